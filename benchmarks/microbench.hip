@@ -1,0 +1,209 @@
+// gfx950 integer-VALU microbenchmarks: measures the roofline denominator
+// (v_mad_u64_u32 issue rate) and the field / point primitive throughput.
+// Build: hipcc -O3 --offload-arch=gfx950 -o microbench microbench.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../bulletproofs_amd/csrc/ec.h"
+using namespace bp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// ---- raw instruction streams: NCH independent chains per lane --------------
+template <int NCH>
+__global__ void k_mad64(uint64_t* out, uint32_t a, uint32_t b, int iters) {
+  uint64_t acc[NCH];
+  for (int i = 0; i < NCH; i++) acc[i] = threadIdx.x + i;
+  uint32_t x = a + threadIdx.x, y = b;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y) : "vcc");
+    }
+  }
+  uint64_t s = 0;
+  for (int i = 0; i < NCH; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NCH>
+__global__ void k_mullo(uint32_t* out, uint32_t a, int iters) {
+  uint32_t acc[NCH];
+  for (int i = 0; i < NCH; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+    }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < NCH; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NCH>
+__global__ void k_mulhi(uint32_t* out, uint32_t a, int iters) {
+  uint32_t acc[NCH];
+  for (int i = 0; i < NCH; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+    }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < NCH; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NCH>
+__global__ void k_mad24(uint32_t* out, uint32_t a, int iters) {
+  uint32_t acc[NCH];
+  for (int i = 0; i < NCH; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+    }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < NCH; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NCH>
+__global__ void k_addc(uint32_t* out, uint32_t a, int iters) {
+  uint32_t acc[NCH];
+  for (int i = 0; i < NCH; i++) acc[i] = threadIdx.x + i + a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(acc[i]) : "v"(a) : "vcc");
+    }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < NCH; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NCH>
+__global__ void k_fma64(double* out, double a, int iters) {
+  double acc[NCH];
+  for (int i = 0; i < NCH; i++) acc[i] = threadIdx.x + i;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+    }
+  }
+  double s = 0;
+  for (int i = 0; i < NCH; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// ---- field / point primitives ------------------------------------------------
+__device__ __forceinline__ u256 seed_fe(uint32_t s) {
+  u256 r;
+  for (int i = 0; i < 8; i++) r.v[i] = s * 2654435761u + i * 0x9E3779B9u;
+  return r;
+}
+__device__ __forceinline__ u256 fq_mul_rows(const u256& a, const u256& b) {
+  uint32_t t[16];
+  mul_wide_rows(t, a, b);
+  return fq_reduce_wide(t);
+}
+// op 0: fq_mul  1: fq_sqr  2: FqMont::mul  3: Fr::mul  4: fq_add  5: fq_sub  6: fq_mul (row-wise arm)
+template <int OP>
+__global__ void __launch_bounds__(256) k_field(uint32_t* out, int iters) {
+  u256 a = seed_fe(threadIdx.x + blockIdx.x * blockDim.x), b = seed_fe(threadIdx.x * 7 + 1);
+  for (int it = 0; it < iters; it++) {
+    if (OP == 0) { a = fq_mul(a, b); b = fq_mul(b, a); }
+    if (OP == 1) { a = fq_sqr(a); b = fq_sqr(b); }
+    if (OP == 2) { a = FqMont::mul(a, b); b = FqMont::mul(b, a); }
+    if (OP == 3) { a = Fr::mul(a, b); b = Fr::mul(b, a); }
+    if (OP == 4) { a = fq_add(a, b); b = fq_add(b, a); }
+    if (OP == 5) { a = fq_sub(a, b); b = fq_sub(b, a); }
+    if (OP == 6) { a = fq_mul_rows(a, b); b = fq_mul_rows(b, a); }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= a.v[i] ^ b.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// op 0: madd chain  1: dbl chain  2: full add chain
+template <int OP>
+__global__ void __launch_bounds__(256) k_point(uint32_t* out, int iters) {
+  affine g = affine_gen();
+  u256 k = seed_fe(threadIdx.x + blockIdx.x * blockDim.x + 1);
+  k.v[7] = 0; k.v[6] = 0; k.v[5] = 0; k.v[4] = 0; k.v[3] = 0; k.v[2] = 0; k.v[1] = 0; k.v[0] = (k.v[0] & 0xffff) + 2;
+  xyzz acc = xyzz_mul_affine(g, k);  // distinct per lane
+  xyzz q = xyzz_dbl(xyzz_dbl(acc));
+  for (int it = 0; it < iters; it++) {
+    if (OP == 0) acc = xyzz_madd(acc, g);
+    if (OP == 1) acc = xyzz_dbl(acc);
+    if (OP == 2) acc = xyzz_add(acc, q);
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= acc.X.v[i] ^ acc.Y.v[i] ^ acc.ZZ.v[i] ^ acc.ZZZ.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <class F>
+static double time_ms(F launch, int reps = 3) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  launch();  // warm
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < reps; r++) {
+    CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  int cus = prop.multiProcessorCount;
+  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d}\n", prop.name, cus, prop.clockRate / 1000);
+  void* buf; CK(hipMalloc(&buf, 64u << 20));
+  const int threads = 256;
+  for (int wps = 1; wps <= 8; wps *= 2) {  // waves per SIMD
+    int blocks = cus * wps;                // 256 threads = 4 waves = 1 wave/SIMD per block
+    const int iters = 4000;
+    double ops = (double)blocks * threads * iters * 8 * 4;
+#define RAW(name, kern, T) { double ms = time_ms([&] { hipLaunchKernelGGL((kern<4>), dim3(blocks), dim3(threads), 0, 0, (T*)buf, 12345, 777, iters); }); \
+      printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"Gops\": %.1f, \"cycles_per_wave_instr\": %.2f}\n", name, wps, ops / ms / 1e6, (double)wps * ms * 1e-3 * prop.clockRate * 1e3 / ((double)iters * 8 * 4 * wps)); }
+    RAW("v_mad_u64_u32", k_mad64, uint64_t)
+#undef RAW
+#define RAW1(name, kern, T, arg) { double ms = time_ms([&] { hipLaunchKernelGGL((kern<4>), dim3(blocks), dim3(threads), 0, 0, (T*)buf, arg, iters); }); \
+      printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"Gops\": %.1f, \"cycles_per_wave_instr\": %.2f}\n", name, wps, ops / ms / 1e6, ms * 1e-3 * prop.clockRate * 1e3 / ((double)iters * 8 * 4)); }
+    RAW1("v_mul_lo_u32", k_mullo, uint32_t, 12345u)
+    RAW1("v_mul_hi_u32", k_mulhi, uint32_t, 12345u)
+    RAW1("v_mad_u32_u24", k_mad24, uint32_t, 12345u)
+    RAW1("v_addc_co_u32", k_addc, uint32_t, 12345u)
+    RAW1("v_fma_f64", k_fma64, double, 1.000001)
+#undef RAW1
+  }
+  for (int wps = 1; wps <= 8; wps *= 2) {
+    int blocks = cus * wps;
+    const int iters = 2000;
+#define FLD(name, OP) { double ms = time_ms([&] { hipLaunchKernelGGL((k_field<OP>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, iters); }); \
+      double n = (double)blocks * threads * iters * 2; \
+      printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"Gop_per_s\": %.2f, \"ns_per_wave_op\": %.1f}\n", name, wps, n / ms / 1e6, ms * 1e6 / (iters * 2.0)); }
+    FLD("fq_mul", 0) FLD("fq_sqr", 1) FLD("fqmont_mul", 2) FLD("fr_mul", 3) FLD("fq_add", 4) FLD("fq_sub", 5) FLD("fq_mul_rows", 6)
+#undef FLD
+  }
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    int blocks = cus * wps;
+    const int iters = 500;
+#define PT(name, OP) { double ms = time_ms([&] { hipLaunchKernelGGL((k_point<OP>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, iters); }); \
+      double n = (double)blocks * threads * iters; \
+      printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"Gop_per_s\": %.3f, \"us_per_wave_op\": %.2f}\n", name, wps, n / ms / 1e6, ms * 1e3 / iters); }
+    PT("xyzz_madd", 0) PT("xyzz_dbl", 1) PT("xyzz_add", 2)
+#undef PT
+  }
+  return 0;
+}

@@ -1,0 +1,515 @@
+// 256-bit modular arithmetic for secp256k1 on 8 x 32-bit limbs (gfx950 VALU).
+//
+// Replaces the arithmetic the reference imports from galois-field-1.0.0
+// (`Fq`, `Fr`, `recip`, `^`; /root/reference/Bulletproofs/Utils.hs:8-9).
+//
+// Every 32x32 product below is written as (u64)a*b + c so that hipcc emits one
+// v_mad_u64_u32 per limb product; everything is fully unrolled and lives in
+// VGPRs.  The same source compiles for the host (tests/hostsim) so that the
+// arithmetic can be checked against the oracle without a GPU.
+//
+//  * Fq  (base field, p = 2^256 - 2^32 - 977).  Values are kept WEAKLY reduced:
+//    any 256-bit integer congruent to the element (so p+3 is a legal encoding
+//    of 3).  Multiplication folds the high half with 2^256 = C (mod p),
+//    C = 2^32 + 977.  fq_canon() gives the unique representative in [0, p).
+//  * Mont<M> (generic 8-limb Montgomery CIOS).  Used for the scalar field Fr
+//    (M = FrMod) and instantiable for Fq (M = FqMod) as the A/B arm of the
+//    field microbenchmark.  Values are canonical (< modulus), in Montgomery
+//    form (x * 2^256 mod m).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define BP_HD __host__ __device__ __forceinline__
+#else
+#define BP_HD inline
+#endif
+
+namespace bp {
+
+struct u256 {
+  uint32_t v[8];
+};
+
+BP_HD u256 u256_zero() {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+  return r;
+}
+BP_HD u256 u256_one() {
+  u256 r = u256_zero();
+  r.v[0] = 1;
+  return r;
+}
+BP_HD bool u256_eq(const u256& a, const u256& b) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i];
+  return d == 0;
+}
+BP_HD bool u256_is_zero(const u256& a) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d |= a.v[i];
+  return d == 0;
+}
+// r = a + b, returns carry out
+BP_HD uint32_t u256_add(u256& r, const u256& a, const u256& b) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a.v[i] + b.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return (uint32_t)c;
+}
+// r = a - b, returns borrow out (0/1)
+BP_HD uint32_t u256_sub(u256& r, const u256& a, const u256& b) {
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)a.v[i] - (int64_t)b.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;  // arithmetic shift: 0 or -1
+  }
+  return (uint32_t)(c & 1);
+}
+// a >= b ?
+BP_HD bool u256_geq(const u256& a, const u256& b) {
+  u256 t;
+  return u256_sub(t, a, b) == 0;
+}
+BP_HD uint32_t u256_bit(const u256& a, int i) { return (a.v[i >> 5] >> (i & 31)) & 1u; }
+
+// acc(64) + ext(32) += a*b : one v_mad_u64_u32 plus one v_addc on the device.
+BP_HD void mac96(uint64_t& acc, uint32_t& ext, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(ext)
+      : "v"(a), "v"(b)
+      : "vcc");
+#else
+  uint64_t p = (uint64_t)a * b;
+  acc += p;
+  ext += (acc < p) ? 1u : 0u;
+#endif
+}
+
+// 8x8 -> 16 limb schoolbook product, row-wise (operand scanning).  Kept as the
+// A/B arm of benchmarks/microbench.hip.
+BP_HD void mul_wide_rows(uint32_t t[16], const u256& a, const u256& b) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    c += (uint64_t)a.v[0] * b.v[j];
+    t[j] = (uint32_t)c;
+    c >>= 32;
+  }
+  t[8] = (uint32_t)c;
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      c += (uint64_t)a.v[i] * b.v[j] + t[i + j];
+      t[i + j] = (uint32_t)c;
+      c >>= 32;
+    }
+    t[i + 8] = (uint32_t)c;
+  }
+}
+
+// 8x8 -> 16 limb product, column-wise (product scanning) into a 96-bit
+// accumulator: the 64-bit addend of v_mad_u64_u32 is the accumulator itself, so
+// no zero-extension moves are needed, and the carry-out feeds one v_addc.
+// The first product of a column cannot overflow (acc < 2^35 after the shift).
+BP_HD void mul_wide(uint32_t t[16], const u256& a, const u256& b) {
+  uint64_t acc = 0;
+  uint32_t ext = 0;
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    const int lo = k < 8 ? 0 : k - 7;
+    const int hi = k < 8 ? k : 7;
+    acc = (uint64_t)a.v[lo] * b.v[k - lo] + acc;
+#pragma unroll
+    for (int i = lo + 1; i <= hi; i++) mac96(acc, ext, a.v[i], b.v[k - i]);
+    t[k] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)ext << 32);
+    ext = 0;
+  }
+  t[15] = (uint32_t)acc;
+}
+
+// 8 -> 16 limb square: off-diagonal products once, doubled, plus the diagonal.
+BP_HD void sqr_wide(uint32_t t[16], const u256& a) {
+  uint64_t c;
+  t[0] = 0;
+  // off-diagonal: sum_{i<j} a_i a_j 2^(32(i+j)), rows i = 0..6
+  c = 0;
+#pragma unroll
+  for (int j = 1; j < 8; j++) {
+    c += (uint64_t)a.v[0] * a.v[j];
+    t[j] = (uint32_t)c;
+    c >>= 32;
+  }
+  t[8] = (uint32_t)c;
+#pragma unroll
+  for (int i = 1; i < 7; i++) {
+    c = 0;
+#pragma unroll
+    for (int j = i + 1; j < 8; j++) {
+      c += (uint64_t)a.v[i] * a.v[j] + t[i + j];
+      t[i + j] = (uint32_t)c;
+      c >>= 32;
+    }
+    t[i + 8] = (uint32_t)c;
+  }
+  t[15] = 0;
+  // double
+#pragma unroll
+  for (int i = 15; i > 0; i--) t[i] = (t[i] << 1) | (t[i - 1] >> 31);
+  // add the diagonal squares
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a.v[i] * a.v[i] + t[2 * i];
+    t[2 * i] = (uint32_t)c;
+    c >>= 32;
+    c += t[2 * i + 1];
+    t[2 * i + 1] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Fq: p = 2^256 - C, C = 2^32 + 977
+// ----------------------------------------------------------------------------
+BP_HD u256 fq_p() {
+  u256 p;
+  p.v[0] = 0xFFFFFC2Fu;
+  p.v[1] = 0xFFFFFFFEu;
+#pragma unroll
+  for (int i = 2; i < 8; i++) p.v[i] = 0xFFFFFFFFu;
+  return p;
+}
+
+// r += k * C for k in {0,1}, r known to be < C-ish after a wrap: touches 3 limbs.
+BP_HD void fq_fold_small(u256& r, uint32_t k) {
+  uint64_t c = (uint64_t)r.v[0] + (k ? 977u : 0u);
+  r.v[0] = (uint32_t)c;
+  c >>= 32;
+  c += (uint64_t)r.v[1] + k;
+  r.v[1] = (uint32_t)c;
+  c >>= 32;
+  r.v[2] += (uint32_t)c;
+}
+
+BP_HD u256 fq_add(const u256& a, const u256& b) {
+  u256 r;
+  uint32_t cy = u256_add(r, a, b);
+  // 2^256 = C (mod p): add cy*C with full ripple, then a rare second wrap
+  uint64_t c = (uint64_t)r.v[0] + (cy ? 977u : 0u);
+  r.v[0] = (uint32_t)c;
+  c >>= 32;
+  c += (uint64_t)r.v[1] + cy;
+  r.v[1] = (uint32_t)c;
+  c >>= 32;
+#pragma unroll
+  for (int i = 2; i < 8; i++) {
+    c += r.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  fq_fold_small(r, (uint32_t)c);
+  return r;
+}
+
+BP_HD u256 fq_sub(const u256& a, const u256& b) {
+  u256 r;
+  uint32_t bw = u256_sub(r, a, b);
+  // wrapped value is a-b+2^256 = a-b+C (mod p): subtract bw*C
+  int64_t c = (int64_t)r.v[0] - (bw ? 977 : 0);
+  r.v[0] = (uint32_t)c;
+  c >>= 32;
+  c += (int64_t)r.v[1] - (int64_t)bw;
+  r.v[1] = (uint32_t)c;
+  c >>= 32;
+#pragma unroll
+  for (int i = 2; i < 8; i++) {
+    c += (int64_t)r.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  // rare second borrow: value is then 2^256 - e with e <= C; only limbs 0,1 move
+  uint32_t bw2 = (uint32_t)(c & 1);
+  c = (int64_t)r.v[0] - (bw2 ? 977 : 0);
+  r.v[0] = (uint32_t)c;
+  c >>= 32;
+  r.v[1] = (uint32_t)((int64_t)r.v[1] - (int64_t)bw2 + c);
+  return r;
+}
+
+BP_HD u256 fq_neg(const u256& a) { return fq_sub(u256_zero(), a); }
+BP_HD u256 fq_dbl(const u256& a) { return fq_add(a, a); }
+
+// Fold a 512-bit product to a weakly reduced 256-bit value.
+BP_HD u256 fq_reduce_wide(const uint32_t t[16]) {
+  uint32_t a[10];
+  // a = lo + hi*977
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)t[8 + i] * 977u + t[i];
+    a[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  a[8] = (uint32_t)c;
+  // a += hi << 32
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a[i + 1] + t[8 + i];
+    a[i + 1] = (uint32_t)c;
+    c >>= 32;
+  }
+  a[9] = (uint32_t)c;
+  // second fold: h2 = a[9]:a[8] (< 2^34), add h2*C = h2*977 + (h2<<32)
+  u256 r;
+  c = (uint64_t)a[8] * 977u + a[0];
+  r.v[0] = (uint32_t)c;
+  c >>= 32;
+  c += (uint64_t)a[9] * 977u + a[1];
+  c += a[8];
+  r.v[1] = (uint32_t)c;
+  c >>= 32;
+  c += (uint64_t)a[2] + a[9];
+  r.v[2] = (uint32_t)c;
+  c >>= 32;
+#pragma unroll
+  for (int i = 3; i < 8; i++) {
+    c += a[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  fq_fold_small(r, (uint32_t)c);
+  return r;
+}
+
+BP_HD u256 fq_mul(const u256& a, const u256& b) {
+  uint32_t t[16];
+  mul_wide(t, a, b);
+  return fq_reduce_wide(t);
+}
+BP_HD u256 fq_sqr(const u256& a) {
+  uint32_t t[16];
+  sqr_wide(t, a);
+  return fq_reduce_wide(t);
+}
+
+// unique representative in [0, p)
+BP_HD u256 fq_canon(const u256& a) {
+  u256 t;
+  uint32_t bw = u256_sub(t, a, fq_p());
+  return bw ? a : t;
+}
+// a == 0 (mod p) for weakly reduced a: a in {0, p}
+BP_HD bool fq_is_zero(const u256& a) {
+  uint32_t z = 0, q = 0;
+  z |= a.v[0];
+  q |= a.v[0] ^ 0xFFFFFC2Fu;
+  z |= a.v[1];
+  q |= a.v[1] ^ 0xFFFFFFFEu;
+#pragma unroll
+  for (int i = 2; i < 8; i++) {
+    z |= a.v[i];
+    q |= ~a.v[i];
+  }
+  return z == 0 || q == 0;
+}
+BP_HD bool fq_eq(const u256& a, const u256& b) { return fq_is_zero(fq_sub(a, b)); }
+
+// a^(2^n)
+BP_HD u256 fq_sqr_n(u256 a, int n) {
+  for (int i = 0; i < n; i++) a = fq_sqr(a);
+  return a;
+}
+
+// a^(p-2) by the standard secp256k1 addition chain (255 squarings, 15 mults).
+// fq_inv(0) = 0.
+BP_HD u256 fq_inv(const u256& a) {
+  u256 x2 = fq_mul(fq_sqr(a), a);
+  u256 x3 = fq_mul(fq_sqr(x2), a);
+  u256 x6 = fq_mul(fq_sqr_n(x3, 3), x3);
+  u256 x9 = fq_mul(fq_sqr_n(x6, 3), x3);
+  u256 x11 = fq_mul(fq_sqr_n(x9, 2), x2);
+  u256 x22 = fq_mul(fq_sqr_n(x11, 11), x11);
+  u256 x44 = fq_mul(fq_sqr_n(x22, 22), x22);
+  u256 x88 = fq_mul(fq_sqr_n(x44, 44), x44);
+  u256 x176 = fq_mul(fq_sqr_n(x88, 88), x88);
+  u256 x220 = fq_mul(fq_sqr_n(x176, 44), x44);
+  u256 x223 = fq_mul(fq_sqr_n(x220, 3), x3);
+  // p-2 = 2^256 - 2^32 - 979: x223 | 0 | 22 ones | 0000 | 1 | 0 | 11 | 0 | 1
+  u256 t = fq_mul(fq_sqr_n(x223, 23), x22);
+  t = fq_mul(fq_sqr_n(t, 5), a);
+  t = fq_mul(fq_sqr_n(t, 3), x2);
+  t = fq_mul(fq_sqr_n(t, 2), a);
+  return t;
+}
+
+// a^((p+1)/4): square root candidate (p = 3 mod 4).  Caller checks r^2 == a.
+BP_HD u256 fq_sqrt_candidate(const u256& a) {
+  u256 x2 = fq_mul(fq_sqr(a), a);
+  u256 x3 = fq_mul(fq_sqr(x2), a);
+  u256 x6 = fq_mul(fq_sqr_n(x3, 3), x3);
+  u256 x9 = fq_mul(fq_sqr_n(x6, 3), x3);
+  u256 x11 = fq_mul(fq_sqr_n(x9, 2), x2);
+  u256 x22 = fq_mul(fq_sqr_n(x11, 11), x11);
+  u256 x44 = fq_mul(fq_sqr_n(x22, 22), x22);
+  u256 x88 = fq_mul(fq_sqr_n(x44, 44), x44);
+  u256 x176 = fq_mul(fq_sqr_n(x88, 88), x88);
+  u256 x220 = fq_mul(fq_sqr_n(x176, 44), x44);
+  u256 x223 = fq_mul(fq_sqr_n(x220, 3), x3);
+  // (p+1)/4 = 2^254 - 2^30 - 244: x223 | 0 | 22 ones | 0000 | 11 | 00
+  u256 t = fq_mul(fq_sqr_n(x223, 23), x22);
+  t = fq_mul(fq_sqr_n(t, 6), x2);
+  t = fq_sqr_n(t, 2);
+  return t;
+}
+
+// ----------------------------------------------------------------------------
+// Generic Montgomery (CIOS), canonical values
+// ----------------------------------------------------------------------------
+struct FrMod {
+  static BP_HD uint32_t m(int i) {
+    constexpr uint32_t t[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
+                               0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    return t[i];
+  }
+  static BP_HD uint32_t r1(int i) {  // 2^256 mod m
+    constexpr uint32_t t[8] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x00000001u, 0, 0, 0};
+    return t[i];
+  }
+  static BP_HD uint32_t r2(int i) {  // 2^512 mod m
+    constexpr uint32_t t[8] = {0x67D7D140u, 0x896CF214u, 0x0E7CF878u, 0x741496C2u,
+                               0x5BCD07C6u, 0xE697F5E4u, 0x81C69BC5u, 0x9D671CD5u};
+    return t[i];
+  }
+  static constexpr uint32_t n0inv = 0x5588B13Fu;  // -m^-1 mod 2^32
+};
+struct FqMod {
+  static BP_HD uint32_t m(int i) {
+    constexpr uint32_t t[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                               0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    return t[i];
+  }
+  static BP_HD uint32_t r1(int i) {
+    constexpr uint32_t t[8] = {0x000003D1u, 0x00000001u, 0, 0, 0, 0, 0, 0};
+    return t[i];
+  }
+  static BP_HD uint32_t r2(int i) {
+    constexpr uint32_t t[8] = {0x000E90A1u, 0x000007A2u, 0x00000001u, 0, 0, 0, 0, 0};
+    return t[i];
+  }
+  static constexpr uint32_t n0inv = 0xD2253531u;
+};
+
+template <class M>
+struct Mont {
+  static BP_HD u256 modulus() {
+    u256 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = M::m(i);
+    return r;
+  }
+  static BP_HD u256 one() {
+    u256 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = M::r1(i);
+    return r;
+  }
+  static BP_HD u256 add(const u256& a, const u256& b) {
+    u256 s, d;
+    uint32_t cy = u256_add(s, a, b);
+    uint32_t bw = u256_sub(d, s, modulus());
+    return (cy || !bw) ? d : s;
+  }
+  static BP_HD u256 sub(const u256& a, const u256& b) {
+    u256 d, e;
+    uint32_t bw = u256_sub(d, a, b);
+    u256_add(e, d, modulus());
+    return bw ? e : d;
+  }
+  static BP_HD u256 neg(const u256& a) { return sub(u256_zero(), a); }
+  // Montgomery product a*b*2^-256 mod m
+  static BP_HD u256 mul(const u256& a, const u256& b) {
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint64_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        c += (uint64_t)a.v[i] * b.v[j] + t[j];
+        t[j] = (uint32_t)c;
+        c >>= 32;
+      }
+      c += t[8];
+      t[8] = (uint32_t)c;
+      t[9] = (uint32_t)(c >> 32);
+      uint32_t q = t[0] * M::n0inv;
+      c = (uint64_t)q * M::m(0) + t[0];
+      c >>= 32;
+#pragma unroll
+      for (int j = 1; j < 8; j++) {
+        c += (uint64_t)q * M::m(j) + t[j];
+        t[j - 1] = (uint32_t)c;
+        c >>= 32;
+      }
+      c += t[8];
+      t[7] = (uint32_t)c;
+      t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    u256 r, d;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    uint32_t bw = u256_sub(d, r, modulus());
+    return (t[8] || !bw) ? d : r;
+  }
+  static BP_HD u256 sqr(const u256& a) { return mul(a, a); }
+  static BP_HD u256 to_mont(const u256& a) {
+    u256 r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.v[i] = M::r2(i);
+    return mul(a, r2);
+  }
+  static BP_HD u256 from_mont(const u256& a) { return mul(a, u256_one()); }
+  // a^e, e given as plain 256-bit integer (square-and-multiply, MSB first)
+  static BP_HD u256 pow(const u256& a, const u256& e) {
+    u256 r = one();
+    for (int i = 255; i >= 0; i--) {
+      r = sqr(r);
+      if (u256_bit(e, i)) r = mul(r, a);
+    }
+    return r;
+  }
+  // a^(m-2); inv(0) = 0
+  static BP_HD u256 inv(const u256& a) {
+    u256 e = modulus();
+    e.v[0] -= 2;  // low limb of both moduli is >= 2
+    return pow(a, e);
+  }
+  // reduce an arbitrary 256-bit integer (< 2^256 < 2m) to canonical
+  static BP_HD u256 reduce_once(const u256& a) {
+    u256 d;
+    uint32_t bw = u256_sub(d, a, modulus());
+    return bw ? a : d;
+  }
+};
+
+typedef Mont<FrMod> Fr;
+typedef Mont<FqMod> FqMont;
+
+}  // namespace bp

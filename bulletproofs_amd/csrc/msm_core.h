@@ -1,0 +1,125 @@
+// Pippenger bucket-MSM building blocks shared by the HIP kernels (msm.hip) and
+// the host simulation used by the CPU tests (tests/hostsim).
+//
+// Replaces `sumExps` (/root/reference/Bulletproofs/Utils.hs:76-80): sum_i e_i*P_i.
+// The reference evaluates N independent double-and-add products; the group
+// element is the same whichever way the sum is associated, so the affine
+// result is identical.
+#pragma once
+#include "ec.h"
+
+namespace bp {
+
+// Signed-digit window plan for 256-bit scalars.
+//   digit_w in [-2^(c-1), 2^(c-1)], sum_w digit_w 2^(c w) = scalar
+//   W = ceil(257 / c) windows: the top window has a spare bit, so no carry leaves it.
+//   bucket index b = |digit| - 1 in [0, 2^(c-1)); digit 0 contributes nothing.
+struct MsmPlan {
+  int c;         // window bits, 1 <= c <= 16
+  int W;         // windows
+  int nb;        // buckets per window = 2^(c-1)
+  int seg;       // buckets per reduction segment (power of two, <= nb)
+  int nseg;      // segments per window = nb / seg
+};
+
+BP_HD MsmPlan msm_plan(int c) {
+  MsmPlan p;
+  p.c = c;
+  p.W = (257 + c - 1) / c;
+  p.nb = 1 << (c - 1);
+  p.seg = p.nb < 32 ? p.nb : 32;
+  p.nseg = p.nb / p.seg;
+  return p;
+}
+
+// Window size for N terms (measured sweet spots).
+inline int msm_choose_c(size_t n) {
+  if (n < 32) return 4;
+  if (n < 128) return 5;
+  if (n < 512) return 7;
+  if (n < 2048) return 8;
+  if (n < 8192) return 10;
+  if (n < 32768) return 11;
+  if (n < 131072) return 13;
+  if (n < 524288) return 14;
+  return 16;
+}
+
+constexpr uint32_t MSM_SKIP = 0xFFFFFFFFu;  // digit 0: no bucket
+constexpr uint32_t MSM_NEG = 0x80000000u;   // entry flag: subtract the point
+
+// Bits [lo, lo + c) of a 256-bit scalar (c <= 16), zero-extended past bit 255.
+BP_HD uint32_t scalar_bits(const u256& s, int lo, int c) {
+  if (lo >= 256) return 0;
+  int limb = lo >> 5, sh = lo & 31;
+  uint64_t w = s.v[limb];
+  if (limb + 1 < 8) w |= (uint64_t)s.v[limb + 1] << 32;
+  return (uint32_t)(w >> sh) & ((1u << c) - 1u);
+}
+
+// Digit of window w given the incoming carry; returns code = bucket | sign flag
+// (or MSM_SKIP) and updates the carry.
+BP_HD uint32_t recode_window(const u256& s, int w, int c, uint32_t& carry) {
+  uint32_t v = scalar_bits(s, w * c, c) + carry;
+  uint32_t half = 1u << (c - 1);
+  if (v > half) {
+    carry = 1;
+    uint32_t mag = (1u << c) - v;  // 1 .. half-1 (or 0 when v == 2^c)
+    return mag == 0 ? MSM_SKIP : ((mag - 1) | MSM_NEG);
+  }
+  carry = 0;
+  return v == 0 ? MSM_SKIP : (v - 1);
+}
+
+// acc += (+/-) P
+BP_HD void bucket_add(xyzz& acc, const affine& p, bool negate) {
+  affine q = p;
+  if (negate) q.y = fq_neg(p.y);  // (0,0) stays the identity: fq_neg(0) = 0
+  acc = xyzz_madd(acc, q);
+}
+
+// Running-sum reduction of one segment of buckets B[0..seg):
+//   S = sum_j B[j],  T = sum_j (j + 1) * B[j]
+template <class LoadBucket>
+BP_HD void segment_reduce(int seg, LoadBucket load, xyzz& S, xyzz& T) {
+  S = xyzz_inf();
+  T = xyzz_inf();
+  for (int j = seg - 1; j >= 0; j--) {
+    S = xyzz_add(S, load(j));
+    T = xyzz_add(T, S);
+  }
+}
+
+// k*P for a small k (< 2^bits), P in XYZZ
+BP_HD xyzz xyzz_mul_small(const xyzz& p, uint32_t k, int bits) {
+  xyzz acc = xyzz_inf();
+  for (int i = bits - 1; i >= 0; i--) {
+    acc = xyzz_dbl(acc);
+    if ((k >> i) & 1u) acc = xyzz_add(acc, p);
+  }
+  return acc;
+}
+
+// Contribution of segment `sidx` (first bucket index sidx*seg, whose weight is
+// sidx*seg + 1):  T + (sidx*seg) * S
+BP_HD xyzz segment_value(const MsmPlan& pl, int sidx, const xyzz& S, const xyzz& T) {
+  if (sidx == 0) return T;
+  int seg_log = 0;
+  while ((1 << seg_log) < pl.seg) seg_log++;
+  xyzz m = xyzz_mul_small(S, (uint32_t)sidx, 16);
+  for (int i = 0; i < seg_log; i++) m = xyzz_dbl(m);
+  return xyzz_add(T, m);
+}
+
+// Horner combine of the per-window sums: sum_w 2^(c w) * Wsum[w]
+template <class LoadW>
+BP_HD xyzz window_combine(const MsmPlan& pl, LoadW load) {
+  xyzz acc = load(pl.W - 1);
+  for (int w = pl.W - 2; w >= 0; w--) {
+    for (int i = 0; i < pl.c; i++) acc = xyzz_dbl(acc);
+    acc = xyzz_add(acc, load(w));
+  }
+  return acc;
+}
+
+}  // namespace bp

@@ -1,0 +1,108 @@
+// Host build of the device arithmetic headers (fe.h, ec.h) for CPU-side tests.
+// TEST INFRASTRUCTURE: lets `pytest -m "not gpu"` check the exact source the
+// HIP kernels compile against the oracle.  Not part of the product path.
+#include <string.h>
+#include "../../bulletproofs_amd/csrc/ec.h"
+using namespace bp;
+
+static u256 ld(const uint8_t* p) { u256 r; memcpy(r.v, p, 32); return r; }
+static void st(uint8_t* p, const u256& a) { memcpy(p, a.v, 32); }
+static affine lda(const uint8_t* p) { affine a; a.x = ld(p); a.y = ld(p + 32); return a; }
+static void sta(uint8_t* p, const affine& a) { st(p, a.x); st(p + 32, a.y); }
+
+extern "C" {
+// op: 0 add 1 sub 2 mul 3 sqr 4 inv 5 sqrt-candidate 6 neg; inputs may be weakly reduced
+void hs_fq_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  u256 x = ld(a), y = ld(b), r;
+  switch (op) {
+    case 0: r = fq_add(x, y); break;
+    case 1: r = fq_sub(x, y); break;
+    case 2: r = fq_mul(x, y); break;
+    case 3: r = fq_sqr(x); break;
+    case 4: r = fq_inv(x); break;
+    case 5: r = fq_sqrt_candidate(x); break;
+    default: r = fq_neg(x); break;
+  }
+  st(out, fq_canon(r));
+}
+int hs_fq_is_zero(const uint8_t* a) { return fq_is_zero(ld(a)); }
+// generic Montgomery arm; which: 0 = Fr, 1 = Fq.  canonical in/out (not Montgomery form)
+void hs_mont_op(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  u256 x = ld(a), y = ld(b), r;
+  if (which == 0) {
+    x = Fr::to_mont(x); y = Fr::to_mont(y);
+    switch (op) {
+      case 0: r = Fr::add(x, y); break;
+      case 1: r = Fr::sub(x, y); break;
+      case 2: r = Fr::mul(x, y); break;
+      case 3: r = Fr::sqr(x); break;
+      case 4: r = Fr::inv(x); break;
+      default: r = Fr::neg(x); break;
+    }
+    st(out, Fr::from_mont(r));
+  } else {
+    x = FqMont::to_mont(x); y = FqMont::to_mont(y);
+    switch (op) {
+      case 0: r = FqMont::add(x, y); break;
+      case 1: r = FqMont::sub(x, y); break;
+      case 2: r = FqMont::mul(x, y); break;
+      case 3: r = FqMont::sqr(x); break;
+      case 4: r = FqMont::inv(x); break;
+      default: r = FqMont::neg(x); break;
+    }
+    st(out, FqMont::from_mont(r));
+  }
+}
+// point ops on affine 64-byte LE (x||y), identity = all zero
+// op: 0 add (via xyzz_add) 1 madd 2 dbl 3 neg 4 mul by scalar k
+void hs_point_op(int op, const uint8_t* p, const uint8_t* q, const uint8_t* k, uint8_t* out) {
+  affine a = lda(p), b = lda(q);
+  xyzz r;
+  switch (op) {
+    case 0: r = xyzz_add(xyzz_from_affine(a), xyzz_from_affine(b)); break;
+    case 1: r = xyzz_madd(xyzz_from_affine(a), b); break;
+    case 2: r = xyzz_dbl(xyzz_from_affine(a)); break;
+    case 3: r = xyzz_from_affine(affine_neg(a)); break;
+    default: r = xyzz_mul_affine(a, ld(k)); break;
+  }
+  sta(out, xyzz_to_affine(r));
+}
+// (k1*P) + (k2*Q) with both partial results left un-normalised (exercises add on general XYZZ)
+void hs_point_lincomb(const uint8_t* p, const uint8_t* k1, const uint8_t* q, const uint8_t* k2, uint8_t* out) {
+  xyzz a = xyzz_mul_affine(lda(p), ld(k1));
+  xyzz b = xyzz_mul_affine(lda(q), ld(k2));
+  sta(out, xyzz_to_affine(xyzz_add(a, b)));
+}
+int hs_on_curve(const uint8_t* p) { return affine_on_curve(lda(p)); }
+}
+
+// ---- serial simulation of the bucket MSM built from msm_core.h bodies ---------
+#include <vector>
+#include "../../bulletproofs_amd/csrc/msm_core.h"
+extern "C" void hs_msm(const uint8_t* scalars, const uint8_t* points, size_t n, int c, uint8_t* out) {
+  MsmPlan pl = msm_plan(c);
+  std::vector<xyzz> buckets((size_t)pl.W * pl.nb, xyzz_inf());
+  for (size_t i = 0; i < n; i++) {
+    u256 s = ld(scalars + 32 * i);
+    affine p = lda(points + 64 * i);
+    uint32_t carry = 0;
+    for (int w = 0; w < pl.W; w++) {
+      uint32_t code = recode_window(s, w, c, carry);
+      if (code == MSM_SKIP) continue;
+      bucket_add(buckets[(size_t)w * pl.nb + (code & ~MSM_NEG)], p, (code & MSM_NEG) != 0);
+    }
+  }
+  std::vector<xyzz> wsum(pl.W);
+  for (int w = 0; w < pl.W; w++) {
+    xyzz acc = xyzz_inf();
+    for (int sg = 0; sg < pl.nseg; sg++) {
+      xyzz S, T;
+      const xyzz* base = &buckets[(size_t)w * pl.nb + (size_t)sg * pl.seg];
+      segment_reduce(pl.seg, [&](int j) { return base[j]; }, S, T);
+      acc = xyzz_add(acc, segment_value(pl, sg, S, T));
+    }
+    wsum[w] = acc;
+  }
+  xyzz r = window_combine(pl, [&](int w) { return wsum[w]; });
+  sta(out, xyzz_to_affine(r));
+}
