@@ -1,0 +1,188 @@
+"""ctypes binding of include/bpgpu.h.  Fails loudly when libbpgpu.so is absent."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbpgpu.so")
+
+P = 2**256 - 2**32 - 977
+R = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+class BpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/bpgpu.h declares
+_u8p = ctypes.c_char_p
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+SYMBOLS = {
+    "bp_version": (_int, []),
+    "bp_ctx_create": (_int, [ctypes.POINTER(_vp), _int]),
+    "bp_ctx_destroy": (None, [_vp]),
+    "bp_last_error": (ctypes.c_char_p, [_vp]),
+    "bp_ctx_sync": (_int, [_vp]),
+    "bp_ctx_stream": (_vp, [_vp]),
+    "bp_point_mul": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
+    "bp_point_add": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
+    "bp_point_neg": (_int, [_vp, _u8p, _sz, _u8p]),
+    "bp_add_two_mul": (_int, [_vp, _u8p, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bp_point_on_curve": (_int, [_vp, _u8p, _sz, _u8p]),
+    "bp_msm": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
+    "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
+}
+
+
+def load_library():
+    """dlopen libbpgpu.so and type every exported symbol.  Raises if the HIP
+    extension has not been built (run `make` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch ships its own HIP runtime (same soname, libamdhip64.so.7).  Two HIP
+    # runtimes in one process cannot both open the GPU, so when torch is around
+    # let it load first: libbpgpu.so then binds to the runtime torch brought.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing for tests/bench only; the engine does not need it
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise BpError("HIP engine not built: %s is missing (run `make`); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+# ---- encodings -----------------------------------------------------------------
+def enc_scalar(s):
+    return int(s).to_bytes(32, "little")
+
+
+def dec_scalar(b):
+    return int.from_bytes(b, "little")
+
+
+def enc_point(pt):
+    """(x, y) or None (identity `O`) -> 64 bytes."""
+    if pt is None:
+        return bytes(64)
+    return int(pt[0]).to_bytes(32, "little") + int(pt[1]).to_bytes(32, "little")
+
+
+def dec_point(b):
+    x = int.from_bytes(b[:32], "little")
+    y = int.from_bytes(b[32:64], "little")
+    return None if (x == 0 and y == 0) else (x, y)
+
+
+def enc_scalars(ss):
+    return b"".join(enc_scalar(s) for s in ss)
+
+
+def enc_points(ps):
+    return b"".join(enc_point(p) for p in ps)
+
+
+def dec_points(buf, n):
+    return [dec_point(buf[64 * i: 64 * i + 64]) for i in range(n)]
+
+
+def dec_scalars(buf, n):
+    return [dec_scalar(buf[32 * i: 32 * i + 32]) for i in range(n)]
+
+
+class Engine:
+    """One engine context (one GPU, one stream).  Method names follow the
+    reference: sum_exps = `sumExps`, add_two_mul_p = `addTwoMulP`
+    (Bulletproofs/Utils.hs:72-80), mul/add/inv = the curve operations."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.bp_ctx_create(ctypes.byref(h), device)
+        if rc != 0:
+            raise BpError("bp_ctx_create(device=%d) failed: %d (no usable GPU?)" % (device, rc))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise BpError("%s failed (%d): %s" % (what, rc, self.lib.bp_last_error(self.h).decode()))
+
+    def sync(self):
+        self._check(self.lib.bp_ctx_sync(self.h), "bp_ctx_sync")
+
+    # -- raw byte-level calls ---------------------------------------------------
+    def point_mul_raw(self, scalars, points, n):
+        out = ctypes.create_string_buffer(64 * n)
+        self._check(self.lib.bp_point_mul(self.h, scalars, points, n, out), "bp_point_mul")
+        return out.raw
+
+    def msm_raw(self, scalars, points, n):
+        out = ctypes.create_string_buffer(64)
+        self._check(self.lib.bp_msm(self.h, scalars, points, n, out), "bp_msm")
+        return out.raw
+
+    def msm_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
+        self._check(self.lib.bp_msm_dev(self.h, d_scalars, d_points, n, window_bits, d_out), "bp_msm_dev")
+
+    # -- list-of-ints conveniences (tests) -----------------------------------------
+    def mul(self, points, scalars):
+        n = len(points)
+        return dec_points(self.point_mul_raw(enc_scalars(scalars), enc_points(points), n), n)
+
+    def add(self, a, b):
+        n = len(a)
+        out = ctypes.create_string_buffer(64 * n)
+        self._check(self.lib.bp_point_add(self.h, enc_points(a), enc_points(b), n, out), "bp_point_add")
+        return dec_points(out.raw, n)
+
+    def inv(self, a):
+        n = len(a)
+        out = ctypes.create_string_buffer(64 * n)
+        self._check(self.lib.bp_point_neg(self.h, enc_points(a), n, out), "bp_point_neg")
+        return dec_points(out.raw, n)
+
+    def add_two_mul_p(self, e0, p0, e1, p1):
+        n = len(e0)
+        out = ctypes.create_string_buffer(64 * n)
+        self._check(self.lib.bp_add_two_mul(self.h, enc_scalars(e0), enc_points(p0), enc_scalars(e1),
+                                            enc_points(p1), n, out), "bp_add_two_mul")
+        return dec_points(out.raw, n)
+
+    def on_curve(self, pts):
+        n = len(pts)
+        out = ctypes.create_string_buffer(n)
+        self._check(self.lib.bp_point_on_curve(self.h, enc_points(pts), n, out), "bp_point_on_curve")
+        return [b != 0 for b in out.raw]
+
+    def sum_exps(self, scalars, points):
+        n = min(len(scalars), len(points))  # Utils.hs:79 truncation
+        return dec_point(self.msm_raw(enc_scalars(scalars[:n]), enc_points(points[:n]), n))
+
+    def field_op(self, field, op, a, b=None):
+        n = len(a)
+        if b is None:
+            b = [0] * n
+        out = ctypes.create_string_buffer(32 * n)
+        self._check(self.lib.bp_field_op(self.h, field, op, enc_scalars(a), enc_scalars(b), n, out), "bp_field_op")
+        return dec_scalars(out.raw, n)

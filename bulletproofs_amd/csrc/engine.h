@@ -1,0 +1,87 @@
+// Internal engine state behind the C ABI of include/bpgpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bpgpu.h"
+#include "ec.h"
+#include "msm_core.h"
+
+namespace bp {
+
+// A grow-only device buffer owned by the context.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t want = need + need / 4;
+    if (hipMalloc(&p, want) != hipSuccess) return -1;
+    bytes = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+// Carves aligned sub-buffers out of one allocation.
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <class T>
+  T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* r = (T*)(base ? base + off : nullptr);
+    off += count * sizeof(T);
+    return r;
+  }
+};
+
+}  // namespace bp
+
+struct bp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bp::DevBuf msm_ws;    // MSM workspace
+  bp::DevBuf io;        // staging for host-pointer entry points
+  bp::DevBuf gen;       // generator tables (verifier / prover)
+  bp::DevBuf vws;       // batch-verifier workspace
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // generator state (filled by bp_ctx_set_generators)
+  uint32_t n_gens = 0;
+};
+
+#define BP_TRY(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+      return BP_ERR_DEVICE;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+#define BP_REQUIRE(cond, msg)          \
+  do {                                 \
+    if (!(cond)) {                     \
+      if (ctx) ctx->err = (msg);       \
+      return BP_ERR_ARG;               \
+    }                                  \
+  } while (0)
+
+namespace bp {
+// msm.hip
+int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
+            void* d_out_xyzz);
+}  // namespace bp

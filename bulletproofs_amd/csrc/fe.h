@@ -124,7 +124,6 @@ BP_HD void mul_wide_rows(uint32_t t[16], const u256& a, const u256& b) {
 // 8x8 -> 16 limb product, column-wise (product scanning) into a 96-bit
 // accumulator: the 64-bit addend of v_mad_u64_u32 is the accumulator itself, so
 // no zero-extension moves are needed, and the carry-out feeds one v_addc.
-// The first product of a column cannot overflow (acc < 2^35 after the shift).
 BP_HD void mul_wide(uint32_t t[16], const u256& a, const u256& b) {
   uint64_t acc = 0;
   uint32_t ext = 0;
@@ -132,9 +131,8 @@ BP_HD void mul_wide(uint32_t t[16], const u256& a, const u256& b) {
   for (int k = 0; k < 15; k++) {
     const int lo = k < 8 ? 0 : k - 7;
     const int hi = k < 8 ? k : 7;
-    acc = (uint64_t)a.v[lo] * b.v[k - lo] + acc;
 #pragma unroll
-    for (int i = lo + 1; i <= hi; i++) mac96(acc, ext, a.v[i], b.v[k - i]);
+    for (int i = lo; i <= hi; i++) mac96(acc, ext, a.v[i], b.v[k - i]);
     t[k] = (uint32_t)acc;
     acc = (acc >> 32) | ((uint64_t)ext << 32);
     ext = 0;

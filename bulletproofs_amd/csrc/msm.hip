@@ -1,0 +1,359 @@
+// Pippenger bucket MSM for secp256k1 on gfx950.
+//
+// Replaces `sumExps` (/root/reference/Bulletproofs/Utils.hs:76-80).
+//
+// Pipeline (all on the context's stream, no host round trip):
+//   1 k_recode        signed c-bit digits per scalar + per-(window,bucket) histogram
+//   2 k_scan          exclusive scan of the histogram per window -> bucket starts
+//   3 k_scatter       counting-sort scatter: (point index | sign) grouped by bucket
+//   4 k_cls_*         counting sort of BUCKETS by population, descending, so that the
+//                     64 lanes of a wave own equally long lists (no divergence tail)
+//   5 k_light         one lane per bucket (population <= LIGHT_MAX): XYZZ mixed adds
+//     k_heavy_*       buckets above LIGHT_MAX are cut into slices, one workgroup per
+//                     slice (wave-level shuffle reduction + LDS across waves)
+//   6 k_seg_reduce    running-sum reduction of 32-bucket segments, one lane each
+//   7 k_window_sum    workgroup tree reduction of the segment values of one window
+//   8 k_final         Horner over the windows + affine normalisation
+#include "engine.h"
+#include "devio.h"
+
+namespace bp {
+
+constexpr int LIGHT_MAX = 254;       // buckets with more entries take the heavy path
+constexpr int NBINS = LIGHT_MAX + 2; // bin 0 = heavy, bin k = population LIGHT_MAX+1-k
+constexpr int SLICE = 2048;          // entries per heavy slice (one 256-thread workgroup)
+
+// ---- 1. digits + histogram --------------------------------------------------
+__global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars, uint32_t n, MsmPlan pl,
+                                               uint32_t* __restrict__ codes, uint32_t* __restrict__ hist) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 s = ld_u256(scalars + (size_t)i * 32);
+  uint32_t carry = 0;
+  for (int w = 0; w < pl.W; w++) {
+    uint32_t code = recode_next(s, pl.c, carry);
+    codes[(size_t)w * n + i] = code;
+    if (code != MSM_SKIP) atomicAdd(&hist[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
+  }
+}
+
+// ---- 2. per-window exclusive scan (one workgroup of 1024 per window) -----------
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t n, MsmPlan pl,
+                                              uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t part[1024];
+  int w = blockIdx.x, t = threadIdx.x;
+  int per = (pl.nb + 1023) / 1024;
+  const uint32_t* h = hist + (size_t)w * pl.nb;
+  uint32_t sum = 0;
+  for (int k = 0; k < per; k++) {
+    int b = t * per + k;
+    if (b < pl.nb) sum += h[b];
+  }
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = (uint32_t)((size_t)w * n) + part[t] - sum;  // exclusive
+  for (int k = 0; k < per; k++) {
+    int b = t * per + k;
+    if (b < pl.nb) {
+      offs[(size_t)w * pl.nb + b] = run;
+      cursor[(size_t)w * pl.nb + b] = run;
+      run += h[b];
+    }
+  }
+}
+
+// ---- 3. scatter ------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ codes, uint32_t n, MsmPlan pl,
+                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  int w = blockIdx.y;
+  if (i >= n) return;
+  uint32_t code = codes[(size_t)w * n + i];
+  if (code == MSM_SKIP) return;
+  uint32_t pos = atomicAdd(&cursor[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
+  sorted[pos] = i | (code & MSM_NEG);
+}
+
+// ---- 4. order buckets by population (descending) -------------------------------
+__device__ __forceinline__ int pop_bin(uint32_t cnt) { return cnt > (uint32_t)LIGHT_MAX ? 0 : (LIGHT_MAX + 1 - (int)cnt); }
+
+__global__ void __launch_bounds__(1024) k_cls_hist(const uint32_t* __restrict__ hist, uint32_t total,
+                                                  uint32_t* __restrict__ bins) {
+  __shared__ uint32_t lh[NBINS];
+  for (int k = threadIdx.x; k < NBINS; k += blockDim.x) lh[k] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < total) atomicAdd(&lh[pop_bin(hist[t])], 1u);
+  __syncthreads();
+  for (int k = threadIdx.x; k < NBINS; k += blockDim.x)
+    if (lh[k]) atomicAdd(&bins[k], lh[k]);
+}
+// bins[0..NBINS) counts -> bins[NBINS..2*NBINS) running cursors (exclusive scan); bins[2*NBINS] = #heavy
+__global__ void k_cls_scan(uint32_t* bins) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < NBINS; k++) {
+      bins[NBINS + k] = run;
+      run += bins[k];
+    }
+    bins[2 * NBINS] = bins[0];
+  }
+}
+__global__ void __launch_bounds__(1024) k_cls_scatter(const uint32_t* __restrict__ hist, uint32_t total,
+                                                     uint32_t* __restrict__ bins, uint32_t* __restrict__ order) {
+  __shared__ uint32_t lh[NBINS];
+  __shared__ uint32_t lbase[NBINS];
+  for (int k = threadIdx.x; k < NBINS; k += blockDim.x) lh[k] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  int bin = 0;
+  uint32_t rank = 0;
+  if (t < total) {
+    bin = pop_bin(hist[t]);
+    rank = atomicAdd(&lh[bin], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < NBINS; k += blockDim.x)
+    if (lh[k]) lbase[k] = atomicAdd(&bins[NBINS + k], lh[k]);
+  __syncthreads();
+  if (t < total) order[lbase[bin] + rank] = t;
+}
+
+// ---- 5a. light buckets: one lane per bucket ----------------------------------------
+__global__ void __launch_bounds__(256) k_light(const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
+                                              const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
+                                              const uint32_t* __restrict__ order, uint32_t total,
+                                              xyzz* __restrict__ buckets) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  uint32_t bid = order[t];
+  uint32_t cnt = hist[bid];
+  if (cnt > (uint32_t)LIGHT_MAX) return;  // heavy path owns it
+  xyzz acc = xyzz_inf();
+  if (cnt) {
+    const uint32_t* lst = sorted + offs[bid];
+    uint32_t e = lst[0];
+    affine p = ld_affine(points + (size_t)(e & ~MSM_NEG) * 64);
+    for (uint32_t k = 0; k < cnt; k++) {
+      affine cur = p;
+      uint32_t ecur = e;
+      if (k + 1 < cnt) {  // prefetch the next point behind the arithmetic
+        e = lst[k + 1];
+        p = ld_affine(points + (size_t)(e & ~MSM_NEG) * 64);
+      }
+      bucket_add(acc, cur, (ecur & MSM_NEG) != 0);
+    }
+  }
+  st_xyzz(&buckets[bid], acc);
+}
+
+// ---- 5b. heavy buckets -----------------------------------------------------------------
+// heavy_off[h] = first slice of heavy bucket h (h-th entry of `order`); heavy_off[nheavy] = total
+__global__ void __launch_bounds__(1024) k_heavy_plan(const uint32_t* __restrict__ hist,
+                                                    const uint32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ bins,
+                                                    uint32_t* __restrict__ heavy_off) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t base;
+  uint32_t nheavy = bins[2 * NBINS];
+  int t = threadIdx.x;
+  if (t == 0) base = 0;
+  __syncthreads();
+  for (uint32_t start = 0; start < nheavy; start += 1024) {
+    uint32_t h = start + t;
+    uint32_t sl = 0;
+    if (h < nheavy) sl = (hist[order[h]] + SLICE - 1) / SLICE;
+    part[t] = sl;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      uint32_t v = t >= d ? part[t - d] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    if (h < nheavy) heavy_off[h] = base + part[t] - sl;
+    __syncthreads();
+    if (t == 1023) base += part[1023];
+    __syncthreads();
+  }
+  if (t == 0) heavy_off[nheavy] = base;
+}
+
+__global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict__ points,
+                                                     const uint32_t* __restrict__ hist,
+                                                     const uint32_t* __restrict__ offs,
+                                                     const uint32_t* __restrict__ sorted,
+                                                     const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ bins,
+                                                     const uint32_t* __restrict__ heavy_off,
+                                                     xyzz* __restrict__ partial) {
+  __shared__ xyzz lds[4];
+  uint32_t nheavy = bins[2 * NBINS];
+  if (nheavy == 0) return;
+  uint32_t total = heavy_off[nheavy];
+  for (uint32_t j = blockIdx.x; j < total; j += gridDim.x) {
+    // largest h with heavy_off[h] <= j
+    uint32_t lo = 0, hi = nheavy - 1;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi + 1) >> 1;
+      if (heavy_off[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    uint32_t bid = order[lo];
+    uint32_t cnt = hist[bid];
+    uint32_t s0 = (j - heavy_off[lo]) * SLICE;
+    uint32_t s1 = s0 + SLICE < cnt ? s0 + SLICE : cnt;
+    const uint32_t* lst = sorted + offs[bid];
+    xyzz acc = xyzz_inf();
+    for (uint32_t k = s0 + threadIdx.x; k < s1; k += blockDim.x) {
+      uint32_t e = lst[k];
+      affine p = ld_affine(points + (size_t)(e & ~MSM_NEG) * 64);
+      bucket_add(acc, p, (e & MSM_NEG) != 0);
+    }
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) st_xyzz(&partial[j], acc);
+  }
+}
+
+// one wave per heavy bucket: sum its slice partials
+__global__ void __launch_bounds__(64) k_heavy_final(const uint32_t* __restrict__ order,
+                                                   const uint32_t* __restrict__ bins,
+                                                   const uint32_t* __restrict__ heavy_off,
+                                                   const xyzz* __restrict__ partial, xyzz* __restrict__ buckets) {
+  uint32_t nheavy = bins[2 * NBINS];
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    uint32_t a = heavy_off[h], b = heavy_off[h + 1];
+    xyzz acc = xyzz_inf();
+    for (uint32_t k = a + threadIdx.x; k < b; k += 64) acc = xyzz_add(acc, ld_xyzz(&partial[k]));
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) st_xyzz(&buckets[order[h]], acc);
+  }
+}
+
+// ---- 6. segment running sums ----------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seg_reduce(const xyzz* __restrict__ buckets, MsmPlan pl,
+                                                   xyzz* __restrict__ segv) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t total = (uint32_t)pl.W * pl.nseg;
+  if (t >= total) return;
+  int sg = t % pl.nseg;
+  const xyzz* base = buckets + (size_t)t * pl.seg;  // (w*nseg + sg)*seg = w*nb + sg*seg
+  xyzz S, T;
+  segment_reduce(pl.seg, [&](int j) { return ld_xyzz(&base[j]); }, S, T);
+  st_xyzz(&segv[t], segment_value(pl, sg, S, T));
+}
+
+// ---- 7. window sums ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_window_sum(const xyzz* __restrict__ segv, MsmPlan pl,
+                                                   xyzz* __restrict__ wsum) {
+  __shared__ xyzz lds[4];
+  int w = blockIdx.x;
+  xyzz acc = xyzz_inf();
+  for (int s = threadIdx.x; s < pl.nseg; s += blockDim.x) acc = xyzz_add(acc, ld_xyzz(&segv[(size_t)w * pl.nseg + s]));
+  acc = block_sum(acc, lds);
+  if (threadIdx.x == 0) st_xyzz(&wsum[w], acc);
+}
+
+// ---- 8. Horner over windows + normalise ------------------------------------------------------
+__global__ void __launch_bounds__(64) k_final(const xyzz* __restrict__ wsum, MsmPlan pl, uint8_t* __restrict__ out_affine,
+                        xyzz* __restrict__ out_xyzz) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xyzz r = window_combine(pl, [&](int w) { return ld_xyzz(&wsum[w]); });
+  if (out_xyzz) st_xyzz(out_xyzz, r);
+  if (out_affine) st_affine(out_affine, xyzz_to_affine(r));
+}
+
+__global__ void k_store_inf(uint8_t* out_affine, xyzz* out_xyzz) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (out_xyzz) st_xyzz(out_xyzz, xyzz_inf());
+  if (out_affine) st_affine(out_affine, affine_inf());
+}
+
+// -------------------------------------------------------------------------------------------------
+int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
+            void* d_out_xyzz) {
+  hipStream_t st = ctx->stream;
+  if (n == 0) {
+    hipLaunchKernelGGL(k_store_inf, dim3(1), dim3(64), 0, st, (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
+    BP_TRY(hipGetLastError());
+    return BP_OK;
+  }
+  if (n >= (1ull << 27)) {
+    ctx->err = "bp_msm: n must be below 2^27";
+    return BP_ERR_ARG;
+  }
+  int c = c_override > 0 ? c_override : msm_choose_c(n);
+  if (c < 1 || c > 16) {
+    ctx->err = "bp_msm: window_bits must be in 1..16";
+    return BP_ERR_ARG;
+  }
+  MsmPlan pl = msm_plan(c);
+  size_t wn = (size_t)pl.W * n;
+  if (wn >= (1ull << 32)) {
+    ctx->err = "bp_msm: windows * n must be below 2^32";
+    return BP_ERR_ARG;
+  }
+  size_t nbt = (size_t)pl.W * pl.nb;
+  size_t max_heavy = wn / (LIGHT_MAX + 1) + 1;
+  size_t max_slices = wn / SLICE + max_heavy + 1;
+
+  // workspace layout (sizes computed with a null base first)
+  uint32_t *codes, *sorted, *hist, *offs, *cursor, *order, *bins, *heavy_off;
+  xyzz *partial, *buckets, *segv, *wsum;
+  auto carve = [&](void* base) {
+    Carver cv(base);
+    hist = cv.take<uint32_t>(nbt);          // zeroed each call
+    bins = cv.take<uint32_t>(2 * NBINS + 8); // zeroed each call (contiguous with hist)
+    size_t zero_end = cv.off;
+    codes = cv.take<uint32_t>(wn);
+    sorted = cv.take<uint32_t>(wn);
+    offs = cv.take<uint32_t>(nbt);
+    cursor = cv.take<uint32_t>(nbt);
+    order = cv.take<uint32_t>(nbt);
+    heavy_off = cv.take<uint32_t>(max_heavy + 1);
+    partial = cv.take<xyzz>(max_slices);
+    buckets = cv.take<xyzz>(nbt);
+    segv = cv.take<xyzz>((size_t)pl.W * pl.nseg);
+    wsum = cv.take<xyzz>(pl.W);
+    (void)zero_end;
+    return cv.off;
+  };
+  size_t need = carve(nullptr);
+  if (ctx->msm_ws.reserve(need) != 0) {
+    ctx->err = "bp_msm: workspace allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  carve(ctx->msm_ws.p);
+  size_t zero_bytes = (size_t)((char*)(bins + 2 * NBINS + 8) - (char*)hist);
+  BP_TRY(hipMemsetAsync(hist, 0, zero_bytes, st));
+
+  uint32_t n32 = (uint32_t)n, nbt32 = (uint32_t)nbt;
+  hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl, codes,
+                     hist);
+  hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, n32, pl, offs, cursor);
+  hipLaunchKernelGGL(k_scatter, dim3((n32 + 255) / 256, pl.W), dim3(256), 0, st, codes, n32, pl, cursor, sorted);
+  hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
+  hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
+  hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
+  hipLaunchKernelGGL(k_light, dim3((nbt32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs,
+                     sorted, order, nbt32, buckets);
+  hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
+  uint32_t hgrid = (uint32_t)(max_slices < 4096 ? max_slices : 4096);
+  hipLaunchKernelGGL(k_heavy_slices, dim3(hgrid), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,
+                     order, bins, heavy_off, partial);
+  uint32_t fgrid = (uint32_t)(max_heavy < 4096 ? max_heavy : 4096);
+  hipLaunchKernelGGL(k_heavy_final, dim3(fgrid), dim3(64), 0, st, order, bins, heavy_off, partial, buckets);
+  uint32_t nsegt = (uint32_t)pl.W * pl.nseg;
+  hipLaunchKernelGGL(k_seg_reduce, dim3((nsegt + 255) / 256), dim3(256), 0, st, buckets, pl, segv);
+  hipLaunchKernelGGL(k_window_sum, dim3(pl.W), dim3(256), 0, st, segv, pl, wsum);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, wsum, pl, (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+}  // namespace bp

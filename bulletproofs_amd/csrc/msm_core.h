@@ -48,19 +48,15 @@ inline int msm_choose_c(size_t n) {
 constexpr uint32_t MSM_SKIP = 0xFFFFFFFFu;  // digit 0: no bucket
 constexpr uint32_t MSM_NEG = 0x80000000u;   // entry flag: subtract the point
 
-// Bits [lo, lo + c) of a 256-bit scalar (c <= 16), zero-extended past bit 255.
-BP_HD uint32_t scalar_bits(const u256& s, int lo, int c) {
-  if (lo >= 256) return 0;
-  int limb = lo >> 5, sh = lo & 31;
-  uint64_t w = s.v[limb];
-  if (limb + 1 < 8) w |= (uint64_t)s.v[limb + 1] << 32;
-  return (uint32_t)(w >> sh) & ((1u << c) - 1u);
-}
-
-// Digit of window w given the incoming carry; returns code = bucket | sign flag
-// (or MSM_SKIP) and updates the carry.
-BP_HD uint32_t recode_window(const u256& s, int w, int c, uint32_t& carry) {
-  uint32_t v = scalar_bits(s, w * c, c) + carry;
+// Next signed digit of the scalar (least significant window first): consumes
+// the low c bits of `s` (s >>= c) and the incoming carry.  Returns
+// code = bucket | sign flag, or MSM_SKIP for a zero digit.  Static limb
+// indices only, so the scalar stays in registers.
+BP_HD uint32_t recode_next(u256& s, int c, uint32_t& carry) {
+  uint32_t v = (s.v[0] & ((1u << c) - 1u)) + carry;
+#pragma unroll
+  for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+  s.v[7] >>= c;
   uint32_t half = 1u << (c - 1);
   if (v > half) {
     carry = 1;

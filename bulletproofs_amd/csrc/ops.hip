@@ -1,0 +1,242 @@
+// Element-wise group / field operations behind the C ABI: batches of independent
+// `mul`, `<>`, `inv`, `addTwoMulP`, `def` and field-law hooks.
+// Reference call sites: /root/reference/Bulletproofs/Utils.hs:72-73,84-85,
+// RangeProof/Internal.hs:183-205, InnerProductProof/Prover.hs:81-92, test/Test/Field.hs.
+#include "engine.h"
+#include "devio.h"
+
+namespace bp {
+
+__global__ void __launch_bounds__(256) k_point_mul(const uint8_t* __restrict__ scalars,
+                                                  const uint8_t* __restrict__ points, uint32_t n,
+                                                  uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)i * 32));
+  affine p = ld_affine(points + (size_t)i * 64);
+  st_affine(out + (size_t)i * 64, xyzz_to_affine(xyzz_mul_affine(p, k)));
+}
+
+__global__ void __launch_bounds__(256) k_point_add(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                  uint32_t n, uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine p = ld_affine(a + (size_t)i * 64), q = ld_affine(b + (size_t)i * 64);
+  st_affine(out + (size_t)i * 64, xyzz_to_affine(xyzz_madd(xyzz_from_affine(p), q)));
+}
+
+__global__ void __launch_bounds__(256) k_point_neg(const uint8_t* __restrict__ a, uint32_t n,
+                                                  uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine p = affine_neg(ld_affine(a + (size_t)i * 64));
+  p.x = fq_canon(p.x);
+  p.y = fq_canon(p.y);
+  st_affine(out + (size_t)i * 64, p);
+}
+
+__global__ void __launch_bounds__(256) k_add_two_mul(const uint8_t* __restrict__ e0, const uint8_t* __restrict__ p0,
+                                                    const uint8_t* __restrict__ e1, const uint8_t* __restrict__ p1,
+                                                    uint32_t n, uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 k0 = Fr::reduce_once(ld_u256(e0 + (size_t)i * 32)), k1 = Fr::reduce_once(ld_u256(e1 + (size_t)i * 32));
+  affine a = ld_affine(p0 + (size_t)i * 64), b = ld_affine(p1 + (size_t)i * 64);
+  // interleaved double-and-add (shared doublings)
+  xyzz acc = xyzz_inf();
+  for (int j = 255; j >= 0; j--) {
+    acc = xyzz_dbl(acc);
+    if (u256_bit(k0, j)) acc = xyzz_madd(acc, a);
+    if (u256_bit(k1, j)) acc = xyzz_madd(acc, b);
+  }
+  st_affine(out + (size_t)i * 64, xyzz_to_affine(acc));
+}
+
+__global__ void __launch_bounds__(256) k_on_curve(const uint8_t* __restrict__ points, uint32_t n,
+                                                 uint8_t* __restrict__ ok) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ok[i] = affine_on_curve(ld_affine(points + (size_t)i * 64)) ? 1 : 0;
+}
+
+template <class F>
+__device__ __forceinline__ u256 mont_op(int op, const u256& a, const u256& b) {
+  u256 x = F::to_mont(a), y = F::to_mont(b), r;
+  switch (op) {
+    case 0: r = F::add(x, y); break;
+    case 1: r = F::sub(x, y); break;
+    case 2: r = F::mul(x, y); break;
+    case 3: r = F::sqr(x); break;
+    case 4: r = F::inv(x); break;
+    default: r = F::neg(x); break;
+  }
+  return F::from_mont(r);
+}
+
+__global__ void __launch_bounds__(256) k_field_op(int field, int op, const uint8_t* __restrict__ a,
+                                                 const uint8_t* __restrict__ b, uint32_t n,
+                                                 uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 x = ld_u256(a + (size_t)i * 32), y = ld_u256(b + (size_t)i * 32), r;
+  if (field == 0) {
+    switch (op) {
+      case 0: r = fq_add(x, y); break;
+      case 1: r = fq_sub(x, y); break;
+      case 2: r = fq_mul(x, y); break;
+      case 3: r = fq_sqr(x); break;
+      case 4: r = fq_inv(x); break;
+      default: r = fq_neg(x); break;
+    }
+    r = fq_canon(r);
+  } else if (field == 1) {
+    r = mont_op<Fr>(op, x, y);
+  } else {
+    r = mont_op<FqMont>(op, x, y);
+  }
+  st_u256(out + (size_t)i * 32, r);
+}
+
+}  // namespace bp
+
+using namespace bp;
+
+// Upload `nin` host arrays, run fn(device pointers, device out), download out.
+template <class Fn>
+static int with_staging(bp_ctx* ctx, std::initializer_list<std::pair<const void*, size_t>> ins, void* out,
+                        size_t out_bytes, Fn fn) {
+  size_t total = 0;
+  std::vector<size_t> offs;
+  for (auto& in : ins) {
+    offs.push_back(total);
+    total += (in.second + 255) & ~(size_t)255;
+  }
+  size_t out_off = total;
+  total += (out_bytes + 255) & ~(size_t)255;
+  if (ctx->io.reserve(total) != 0) {
+    ctx->err = "staging allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  char* base = (char*)ctx->io.p;
+  std::vector<const uint8_t*> dptr;
+  size_t k = 0;
+  for (auto& in : ins) {
+    if (in.second) BP_TRY(hipMemcpyAsync(base + offs[k], in.first, in.second, hipMemcpyHostToDevice, ctx->stream));
+    dptr.push_back((const uint8_t*)(base + offs[k]));
+    k++;
+  }
+  int rc = fn(dptr, (uint8_t*)(base + out_off));
+  if (rc != BP_OK) return rc;
+  if (out_bytes) BP_TRY(hipMemcpyAsync(out, base + out_off, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  BP_TRY(hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+#define BP_CHECK_N(n) BP_REQUIRE((n) < (1ull << 31), "n must be below 2^31")
+#define GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, ctx->stream
+
+extern "C" {
+
+int bp_point_mul(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (scalars && points && out), "null pointer");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{scalars, n * 32}, {points, n * 64}}, out, n * 64,
+                      [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+                        hipLaunchKernelGGL(k_point_mul, GRID(n), d[0], d[1], (uint32_t)n, dout);
+                        BP_TRY(hipGetLastError());
+                        return BP_OK;
+                      });
+}
+
+int bp_point_add(bp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (a && b && out), "null pointer");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{a, n * 64}, {b, n * 64}}, out, n * 64,
+                      [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+                        hipLaunchKernelGGL(k_point_add, GRID(n), d[0], d[1], (uint32_t)n, dout);
+                        BP_TRY(hipGetLastError());
+                        return BP_OK;
+                      });
+}
+
+int bp_point_neg(bp_ctx* ctx, const uint8_t* a, size_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (a && out), "null pointer");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{a, n * 64}}, out, n * 64, [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+    hipLaunchKernelGGL(k_point_neg, GRID(n), d[0], (uint32_t)n, dout);
+    BP_TRY(hipGetLastError());
+    return BP_OK;
+  });
+}
+
+int bp_add_two_mul(bp_ctx* ctx, const uint8_t* e0, const uint8_t* p0, const uint8_t* e1, const uint8_t* p1,
+                   size_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (e0 && p0 && e1 && p1 && out), "null pointer");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{e0, n * 32}, {p0, n * 64}, {e1, n * 32}, {p1, n * 64}}, out, n * 64,
+                      [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+                        hipLaunchKernelGGL(k_add_two_mul, GRID(n), d[0], d[1], d[2], d[3], (uint32_t)n, dout);
+                        BP_TRY(hipGetLastError());
+                        return BP_OK;
+                      });
+}
+
+int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (points && ok), "null pointer");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{points, n * 64}}, ok, n, [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+    hipLaunchKernelGGL(k_on_curve, GRID(n), d[0], (uint32_t)n, dout);
+    BP_TRY(hipGetLastError());
+    return BP_OK;
+  });
+}
+
+int bp_field_op(bp_ctx* ctx, int field, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (a && b && out), "null pointer");
+  BP_REQUIRE(field >= 0 && field <= 2 && op >= 0 && op <= 5, "bad field/op selector");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{a, n * 32}, {b, n * 32}}, out, n * 32,
+                      [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+                        hipLaunchKernelGGL(k_field_op, GRID(n), field, op, d[0], d[1], (uint32_t)n, dout);
+                        BP_TRY(hipGetLastError());
+                        return BP_OK;
+                      });
+}
+
+int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(d_out && (n == 0 || (d_scalars && d_points)), "null pointer");
+  BP_REQUIRE(window_bits >= 0 && window_bits <= 16, "window_bits must be 0 (auto) or 1..16");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_run(ctx, d_scalars, d_points, n, window_bits, d_out, nullptr);
+}
+
+int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(out && (n == 0 || (scalars && points)), "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{scalars, n * 32}, {points, n * 64}}, out, 64,
+                      [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+                        return msm_run(ctx, d[0], d[1], n, 0, dout, nullptr);
+                      });
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+/* bpgpu.h - C ABI of the MI355X engine for the elliptic-curve hot path of
+ * sdiehl/bulletproofs (secp256k1).
+ *
+ * This is the boundary a `foreign import ccall` in the reference's Haskell
+ * modules binds.  The reference has no FFI today: each
+ * entry point below names the pure Haskell function (file:line under
+ * /root/reference) whose evaluation it replaces.
+ *
+ * Encodings (all little-endian, caller-owned buffers):
+ *   scalar  : 32 bytes, integer in [0, 2^256); values >= r are accepted and act
+ *             modulo the group order r (as `mul` does for an `Fr`).
+ *   point   : 64 bytes, affine x || y, each 32 bytes, canonical (< p).  The
+ *             identity `O` (`mempty`) is 64 zero bytes ((0,0) is not on the curve).
+ *   Outputs are always canonical; points are affine-normalised.
+ *
+ * Every function returns BP_OK (0) or a negative error; bp_last_error(ctx)
+ * returns a message for the most recent failure on that context.  Nothing
+ * throws across this boundary.  A context is bound to one GPU and one HIP
+ * stream and is not thread-safe: use one context per host thread (the
+ * reference is single-threaded, so there are no concurrency semantics to keep).
+ *
+ * Entry points come in two flavours:
+ *   bp_*      host pointers in, host pointers out (what the Haskell shim calls);
+ *   bp_*_dev  device pointers (hipMalloc memory on ctx's device), asynchronous on
+ *             the context's stream - for callers that keep data resident in HBM.
+ */
+#ifndef BPGPU_H
+#define BPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_OK 0
+#define BP_ERR_ARG (-1)     /* bad argument (null pointer, size out of range, ...) */
+#define BP_ERR_DEVICE (-2)  /* HIP runtime error */
+#define BP_ERR_NOMEM (-3)   /* device allocation failed */
+#define BP_ERR_STATE (-4)   /* call out of order (e.g. generators not set) */
+
+typedef struct bp_ctx bp_ctx;
+
+/* ABI version of this header (major*100 + minor). */
+int bp_version(void);
+
+/* Create / destroy an engine context on HIP device `device`. */
+int bp_ctx_create(bp_ctx** out, int device);
+void bp_ctx_destroy(bp_ctx* ctx);
+const char* bp_last_error(const bp_ctx* ctx);
+/* Block until all work queued on the context's stream has finished. */
+int bp_ctx_sync(bp_ctx* ctx);
+/* The context's hipStream_t, as an opaque pointer. */
+void* bp_ctx_stream(bp_ctx* ctx);
+
+/* ---- element-wise group operations (batches of n independent operations) ----
+ *
+ * bp_point_mul      out[i] = scalars[i] * points[i]
+ *                   replaces `mul` (Data.Curve.Weierstrass, imported at
+ *                   Bulletproofs/Utils.hs:9; call sites Utils.hs:73,
+ *                   MultiRangeProof/Prover.hs:107, RangeProof/Internal.hs:185-205).
+ * bp_point_add      out[i] = a[i] + b[i]
+ *                   replaces `<>` / `add` (Utils.hs:73,78; test/Test/Field.hs:23).
+ * bp_point_neg      out[i] = -a[i]
+ *                   replaces `inv` (RangeProof/Internal.hs:187,196).
+ * bp_add_two_mul    out[i] = e0[i]*p0[i] + e1[i]*p1[i]
+ *                   replaces `addTwoMulP` (Utils.hs:72-73), incl. the generator
+ *                   folds of InnerProductProof/Prover.hs:81-82.
+ * bp_point_on_curve ok[i] = 1 if points[i] satisfies y^2 = x^3 + 7 or is O
+ *                   replaces `def` (Utils.hs:42).
+ */
+int bp_point_mul(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
+int bp_point_add(bp_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+int bp_point_neg(bp_ctx* ctx, const uint8_t* a, size_t n, uint8_t* out);
+int bp_add_two_mul(bp_ctx* ctx, const uint8_t* e0, const uint8_t* p0, const uint8_t* e1, const uint8_t* p1,
+                   size_t n, uint8_t* out);
+int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok);
+
+/* ---- multi-scalar multiplication ----
+ *
+ * bp_msm            out = sum_i scalars[i] * points[i]
+ *                   replaces `sumExps` (Bulletproofs/Utils.hs:76-80).  The
+ *                   caller truncates to the shorter list as the reference does
+ *                   (Utils.hs:79); n = 0 gives O (Utils.hs:80).
+ * bp_msm_dev        same with device-resident inputs/outputs; `d_out` receives
+ *                   one 64-byte affine point.  window_bits = 0 picks the window
+ *                   size from n; 1..16 forces it (benchmark / test knob).
+ */
+int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
+int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
+
+/* ---- field arithmetic self-test hooks (used by the parity tests) ----
+ * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a)
+ * field: 0 = Fq (base field, pseudo-Mersenne path), 1 = Fr (Montgomery path),
+ *        2 = Fq through the generic Montgomery path
+ * a, b, out: n canonical 32-byte elements.  Replaces `+ - * recip negate` on
+ * `Fr`/`Fq` (galois-field, imported at Utils.hs:8; laws in test/Test/Field.hs:39-64).
+ */
+int bp_field_op(bp_ctx* ctx, int field, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPGPU_H */

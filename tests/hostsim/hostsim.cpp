@@ -87,7 +87,7 @@ extern "C" void hs_msm(const uint8_t* scalars, const uint8_t* points, size_t n, 
     affine p = lda(points + 64 * i);
     uint32_t carry = 0;
     for (int w = 0; w < pl.W; w++) {
-      uint32_t code = recode_window(s, w, c, carry);
+      uint32_t code = recode_next(s, c, carry);
       if (code == MSM_SKIP) continue;
       bucket_add(buckets[(size_t)w * pl.nb + (code & ~MSM_NEG)], p, (code & MSM_NEG) != 0);
     }

@@ -1,0 +1,142 @@
+"""CPU tests of the device arithmetic headers (fe.h, ec.h, msm_core.h) compiled
+for the host (tests/hostsim), against the oracle and the golden vectors."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import bp_oracle as o
+from util import golden, ux, up
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P, R = o.P, o.R
+
+
+@pytest.fixture(scope="module")
+def hs():
+    so = os.path.join(HERE, "hostsim", "libhostsim.so")
+    src = os.path.join(HERE, "hostsim", "hostsim.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+def b(x):
+    return int(x).to_bytes(32, "little")
+
+
+def pb(pt):
+    return bytes(64) if pt is None else b(pt[0]) + b(pt[1])
+
+
+def dp(raw):
+    x, y = int.from_bytes(raw[:32], "little"), int.from_bytes(raw[32:64], "little")
+    return None if x == 0 and y == 0 else (x, y)
+
+
+def fq(hs, op, a, c=0):
+    out = ctypes.create_string_buffer(32)
+    hs.hs_fq_op(op, b(a), b(c), out)
+    return int.from_bytes(out.raw, "little")
+
+
+def mont(hs, which, op, a, c=0):
+    out = ctypes.create_string_buffer(32)
+    hs.hs_mont_op(which, op, b(a), b(c), out)
+    return int.from_bytes(out.raw, "little")
+
+
+def test_fq_weak_representation_edges(hs):
+    rng = random.Random(7)
+    edge = [0, 1, 2, P - 1, P, P + 1, 2**256 - 1, 2**256 - 2, 2**32 + 977, 2**32 + 976, P - 2**32, 2**255, 977]
+    vals = edge + [rng.randrange(2**256) for _ in range(120)]
+    for a in vals:
+        for c in edge + [rng.choice(vals) for _ in range(6)]:
+            assert fq(hs, 0, a, c) == (a + c) % P
+            assert fq(hs, 1, a, c) == (a - c) % P
+            assert fq(hs, 2, a, c) == (a * c) % P
+        assert fq(hs, 3, a) == a * a % P
+        assert fq(hs, 6, a) == (-a) % P
+        assert bool(hs.hs_fq_is_zero(b(a))) == (a % P == 0)
+    for a in vals[:40]:
+        assert fq(hs, 4, a) == (pow(a, -1, P) if a % P else 0)
+        if pow(a % P, (P - 1) // 2, P) == 1:
+            assert fq(hs, 5, a) ** 2 % P == a % P
+
+
+@pytest.mark.parametrize("which,mod", [(0, R), (1, P)])
+def test_montgomery_field_laws(hs, which, mod):
+    """test/Test/Field.hs:39-64 field laws + exact values."""
+    rng = random.Random(8 + which)
+    ev = [0, 1, 2, mod - 1, mod - 2] + [rng.randrange(mod) for _ in range(60)]
+    for a in ev:
+        for c in ev[:6] + [rng.choice(ev) for _ in range(4)]:
+            assert mont(hs, which, 0, a, c) == (a + c) % mod
+            assert mont(hs, which, 1, a, c) == (a - c) % mod
+            assert mont(hs, which, 2, a, c) == (a * c) % mod
+        assert mont(hs, which, 3, a) == a * a % mod
+        assert mont(hs, which, 5, a) == (-a) % mod
+    for a in ev[:20]:
+        assert mont(hs, which, 4, a) == (pow(a, -1, mod) if a else 0)
+
+
+def test_golden_field(hs):
+    g = golden()
+    for e in g["fq"]:
+        a, c = ux(e["a"]), ux(e["b"])
+        assert fq(hs, 0, a, c) == ux(e["add"]) and fq(hs, 1, a, c) == ux(e["sub"])
+        assert fq(hs, 2, a, c) == ux(e["mul"]) and fq(hs, 4, a) == ux(e["inv"])
+    for e in g["fr"]:
+        a, c = ux(e["a"]), ux(e["b"])
+        assert mont(hs, 0, 0, a, c) == ux(e["add"]) and mont(hs, 0, 1, a, c) == ux(e["sub"])
+        assert mont(hs, 0, 2, a, c) == ux(e["mul"]) and mont(hs, 0, 4, a) == ux(e["inv"])
+
+
+def pop(hs, op, p, q=None, k=0):
+    out = ctypes.create_string_buffer(64)
+    hs.hs_point_op(op, pb(p), pb(q), b(k), out)
+    return dp(out.raw)
+
+
+def test_group_law_total(hs):
+    rng = random.Random(9)
+    G = o.GEN
+    pts = [None, G, o.point_neg(G)] + [o.point_mul(G, rng.randrange(1, R)) for _ in range(8)]
+    for p in pts:
+        assert pop(hs, 2, p) == o.point_add(p, p)
+        assert pop(hs, 3, p) == o.point_neg(p)
+        assert pop(hs, 0, p, o.point_neg(p)) is None
+        for q in pts:
+            assert pop(hs, 0, p, q) == o.point_add(p, q)
+            assert pop(hs, 1, p, q) == o.point_add(p, q)
+    for k in [0, 1, 2, R - 1, R - 2] + [rng.randrange(R) for _ in range(6)]:
+        for p in pts[:4]:
+            assert pop(hs, 4, p, None, k) == o.point_mul(p, k)
+    for e in golden()["kG"]:
+        assert pop(hs, 4, G, None, ux(e["k"])) == up(e["P"])
+    assert hs.hs_on_curve(pb(G)) == 1 and hs.hs_on_curve(pb((5, 7))) == 0 and hs.hs_on_curve(pb(None)) == 1
+
+
+def msm(hs, es, ps, c):
+    out = ctypes.create_string_buffer(64)
+    hs.hs_msm(b"".join(b(e) for e in es), b"".join(pb(p) for p in ps), len(es), c, out)
+    return dp(out.raw)
+
+
+@pytest.mark.parametrize("c", [1, 3, 4, 7, 10, 13, 16])
+def test_bucket_msm_bodies(hs, c):
+    rng = random.Random(30 + c)
+    base = [o.point_mul(o.GEN, rng.randrange(1, R)) for _ in range(10)]
+    for n in [0, 1, 2, 9, 20]:
+        ps = [rng.choice(base + [None]) for _ in range(n)]
+        es = [rng.choice([0, 1, 2, R - 1, R - 2, 2**255, rng.randrange(R), rng.randrange(R), rng.randrange(2**64)])
+              for _ in range(n)]
+        assert msm(hs, es, ps, c) == o.sum_exps(es, ps)
+    p = base[0]
+    assert msm(hs, [5, R - 5], [p, p], c) is None
+    assert msm(hs, [7, 7, 7], [p, p, p], c) == o.point_mul(p, 21)
+    if c == 7:
+        for case in golden()["sumExps"]:
+            assert msm(hs, [ux(s) for s in case["scalars"]], [up(q) for q in case["points"]], c) == up(case["result"])

@@ -1,0 +1,237 @@
+"""CPU tests of the oracle: pinned against OpenSSL's secp256k1, the committed
+golden vectors, and the properties the reference's own test-suite states
+(test/Test/Field.hs, test/Test/Protocol/RangeProof.hs)."""
+import ctypes
+import ctypes.util
+import random
+
+import pytest
+
+import bp_oracle as o
+from util import golden, ux, up, load_proof, load_blinders
+
+
+# ---- independent pin: OpenSSL libcrypto --------------------------------------------
+class OpenSSL:
+    def __init__(self):
+        name = ctypes.util.find_library("crypto")
+        if not name:
+            pytest.skip("libcrypto not present")
+        L = ctypes.CDLL(name)
+        vp = ctypes.c_void_p
+        L.EC_GROUP_new_by_curve_name.restype = vp
+        L.EC_POINT_new.restype = vp
+        L.EC_POINT_new.argtypes = [vp]
+        L.BN_new.restype = vp
+        L.BN_bin2bn.restype = vp
+        L.BN_bin2bn.argtypes = [ctypes.c_char_p, ctypes.c_int, vp]
+        L.BN_CTX_new.restype = vp
+        L.EC_POINT_mul.argtypes = [vp] * 6
+        L.EC_POINT_add.argtypes = [vp] * 5
+        L.EC_POINT_set_affine_coordinates.argtypes = [vp] * 5
+        L.EC_POINT_get_affine_coordinates.argtypes = [vp] * 5
+        L.EC_POINT_is_at_infinity.argtypes = [vp, vp]
+        L.BN_bn2binpad.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+        self.L = L
+        self.g = L.EC_GROUP_new_by_curve_name(714)  # NID_secp256k1
+        self.ctx = L.BN_CTX_new()
+
+    def bn(self, v):
+        return self.L.BN_bin2bn(v.to_bytes(32, "big"), 32, None)
+
+    def pt(self, p):
+        q = self.L.EC_POINT_new(self.g)
+        assert self.L.EC_POINT_set_affine_coordinates(self.g, q, self.bn(p[0]), self.bn(p[1]), self.ctx) == 1
+        return q
+
+    def out(self, q):
+        if self.L.EC_POINT_is_at_infinity(self.g, q):
+            return None
+        x, y = self.L.BN_new(), self.L.BN_new()
+        assert self.L.EC_POINT_get_affine_coordinates(self.g, q, x, y, self.ctx) == 1
+        bx, by = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        self.L.BN_bn2binpad(x, bx, 32)
+        self.L.BN_bn2binpad(y, by, 32)
+        return int.from_bytes(bx.raw, "big"), int.from_bytes(by.raw, "big")
+
+    def mul(self, p, k):
+        q = self.L.EC_POINT_new(self.g)
+        assert self.L.EC_POINT_mul(self.g, q, None, self.pt(p), self.bn(k), self.ctx) == 1
+        return self.out(q)
+
+    def add(self, a, b):
+        q = self.L.EC_POINT_new(self.g)
+        assert self.L.EC_POINT_add(self.g, q, self.pt(a), self.pt(b), self.ctx) == 1
+        return self.out(q)
+
+
+@pytest.fixture(scope="module")
+def ossl():
+    return OpenSSL()
+
+
+def test_point_mul_vs_openssl(ossl):
+    rng = random.Random(11)
+    base = o.GEN
+    for _ in range(25):
+        k = rng.randrange(1, o.R)
+        assert o.point_mul(base, k) == ossl.mul(base, k)
+        base = o.point_mul(o.GEN, rng.randrange(1, o.R))
+    assert o.point_mul(o.GEN, o.R) is None
+
+
+def test_point_add_vs_openssl(ossl):
+    rng = random.Random(12)
+    for _ in range(25):
+        a = o.point_mul(o.GEN, rng.randrange(1, o.R))
+        b = o.point_mul(o.GEN, rng.randrange(1, o.R))
+        assert o.point_add(a, b) == ossl.add(a, b)
+        assert o.point_add(a, a) == ossl.add(a, a)
+        assert o.point_add(a, o.point_neg(a)) is None
+
+
+def test_known_kg_constants():
+    # 2G and 3G of secp256k1 (widely published)
+    assert o.point_mul(o.GEN, 2) == (
+        0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5,
+        0x1AE168FEA63DC339A3C58419466CEAEEF7F632653266D0E1236431A950CFE52A)
+    assert o.point_mul(o.GEN, 3) == (
+        0xF9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9,
+        0x388F7B0F632DE8140FE337E62A37F3566500A99934C2231B6CB9FD7584B8E672)
+
+
+# ---- golden vectors ---------------------------------------------------------------------
+def test_golden_generators_and_points():
+    g = golden()
+    assert up(g["h"]) == o.h()
+    assert [up(p) for p in g["gs"]] == o.gs(4)
+    assert [up(p) for p in g["hs"]] == o.hs(4)
+    for e in g["kG"]:
+        assert o.point_mul(o.GEN, ux(e["k"])) == up(e["P"])
+    for c in g["sumExps"]:
+        assert o.sum_exps([ux(s) for s in c["scalars"]], [up(p) for p in c["points"]]) == up(c["result"])
+
+
+def test_golden_bench_proof():
+    """The reference's bench input (bench/Bench/RangeProof.hs:10-14)."""
+    b = golden()["bench_proof"]
+    pr = o.mrp_generate_proof_unsafe(2**64, [(b["v"], b["vBlinding"])], *load_blinders(b["blinders"]))
+    assert pr == load_proof(b["proof"])
+    assert o.commit(b["v"], b["vBlinding"]) == up(b["vCommit"])
+    assert o.rp_verify_proof(2**64, up(b["vCommit"]), pr) is True
+
+
+def test_golden_multi_proof():
+    m = golden()["multi_proof"]
+    vs = [(ux(v), ux(b)) for v, b in m["vs"]]
+    pr = o.mrp_generate_proof(2**8, vs, *load_blinders(m["blinders"]))
+    assert pr == load_proof(m["proof"])
+    assert o.mrp_verify_proof(2**8, [up(p) for p in m["vCommits"]], pr) is True
+
+
+# ---- properties restated from the reference's tests ------------------------------------------
+def test_prop_add_sub_mod():
+    """test/Test/Field.hs:15-33."""
+    rng = random.Random(13)
+    for _ in range(5):
+        x, y = rng.randrange(o.R), rng.randrange(o.R)
+        assert o.point_mul(o.GEN, (x + y) % o.R) == o.point_add(o.point_mul(o.GEN, x), o.point_mul(o.GEN, y))
+        assert o.point_mul(o.GEN, (x - y) % o.R) == o.point_add(o.point_mul(o.GEN, x),
+                                                                 o.point_neg(o.point_mul(o.GEN, y)))
+
+
+def test_sum_exps_truncation_and_empty():
+    """Utils.hs:79-80."""
+    p = o.gs(3)
+    assert o.sum_exps([], p) is None
+    assert o.sum_exps([5], []) is None
+    assert o.sum_exps([5, 7, 9], p[:2]) == o.sum_exps([5, 7], p[:2])
+    assert o.sum_exps([5, 7], p) == o.sum_exps([5, 7], p[:2])
+
+
+def test_power_vector_zero_case():
+    """Utils.hs:50-52: 0^0 = 0."""
+    assert o.power_vector(0, 3) == [0, 0, 0]
+    assert o.power_vector(2, 4) == [1, 2, 4, 8]
+    assert o.power_vector(1, 3) == [1, 1, 1]
+
+
+def test_bit_vector_algebra():
+    """test/Test/Protocol/RangeProof.hs:29-103."""
+    rng = random.Random(14)
+    for _ in range(6):
+        n = 2 ** rng.randrange(0, 8)
+        v = rng.randrange(1, 2**n)
+        a_l = o.reversed_encode_bit(n, v)
+        a_r = o.complementary_vector(a_l)
+        assert o.dot(a_l, a_r) == 0
+        assert o.hadamard(a_l, a_r) == [0] * n
+        assert o.dot(a_l, o.power_vector(2, n)) == v % o.R
+        y, z = rng.randrange(o.R), rng.randrange(o.R)
+        yn = o.power_vector(y, n)
+        assert o.dot(o.vsub(o.vsub(a_l, o.power_vector(1, n)), a_r), yn) == 0
+        # obfuscateEncodedBitsSingle == z^2 v + delta n 1 y z
+        z1n = [z] * n
+        lhs = o.dot(o.vsub(a_l, z1n),
+                    o.vadd(o.hadamard(yn, o.vadd(a_r, z1n)), [z * z * t % o.R for t in o.power_vector(2, n)]))
+        assert lhs == (z * z * v + o.delta(n, 1, y, z)) % o.R
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (4, 1), (8, 3), (16, 1)])
+def test_completeness_and_soundness(n, m):
+    """test/Test/Protocol/RangeProof.hs:112-145,183-221 (small sizes; the
+    reference samples n in {1..128}, m in 1..10)."""
+    rng = random.Random(100 * n + m)
+    ub = 2**n
+    vs = [(rng.randrange(0, 2**n), rng.randrange(1, o.R)) for _ in range(m)]
+    m2 = 2 ** o.log2_ceil(m)
+    pr = o.mrp_generate_proof(ub, vs, *o.draw_blinders(rng, n * m2))
+    vcs = [o.commit(v, b) for v, b in vs]
+    y = o.shamir_y(pr["aCommit"], pr["sCommit"])
+    z = o.shamir_z(pr["aCommit"], pr["sCommit"], y)
+    x = o.shamir_x(pr["aCommit"], pr["sCommit"], pr["t1Commit"], pr["t2Commit"], y, z)
+    padded = vcs + [None] * (m2 - m)
+    assert o.verify_t_poly(n, padded, pr, x, y, z)
+    assert o.verify_lr_commitment(n, m2, pr, x, y, z)
+    assert o.mrp_verify_proof(ub, vcs, pr)
+    bad = [o.commit(vs[0][0] + 1, vs[0][1])] + vcs[1:]
+    assert not o.mrp_verify_proof(ub, bad, pr)
+    if n > 1:
+        assert not o.mrp_verify_proof(2 ** (n // 2), vcs, pr)  # different upper bound
+
+
+def test_error_paths():
+    """test/Test/Protocol/RangeProof.hs:147-171."""
+    rng = random.Random(15)
+    bl = o.draw_blinders(rng, 8)
+    with pytest.raises(o.RangeProofError) as e:
+        o.mrp_generate_proof(2**8, [(300, 5)], *bl)
+    assert e.value.args[0][0] == "ValuesNotInRange"
+    with pytest.raises(o.RangeProofError) as e:
+        o.mrp_generate_proof(o.R + 1, [(3, 5)], *bl)
+    assert e.value.args[0][0] == "UpperBoundTooLarge"
+    with pytest.raises(o.RangeProofError) as e:
+        o.mrp_generate_proof(2**6, [(3, 5)], *bl)  # n = 6 is not a power of two
+    assert e.value.args[0][0] == "NNotPowerOf2"
+
+
+def test_ipp_standalone():
+    """InnerProductProof generateProof/verifyProof on an arbitrary base."""
+    rng = random.Random(16)
+    for n in [1, 2, 8]:
+        g, hh = o.gs(n), o.hs(n)
+        u = o.point_mul(o.GEN, rng.randrange(1, o.R))
+        ls = [rng.randrange(o.R) for _ in range(n)]
+        rs = [rng.randrange(o.R) for _ in range(n)]
+        c = o.point_add(o.point_add(o.sum_exps(ls, g), o.sum_exps(rs, hh)), o.point_mul(u, o.dot(ls, rs)))
+        pr = o.ipp_generate_proof(g, hh, u, c, ls, rs)
+        assert len(pr["lCommits"]) == n.bit_length() - 1
+        assert o.ipp_verify_proof(n, g, hh, u, c, pr)
+        pr2 = dict(pr, l=(pr["l"] + 1) % o.R)
+        assert not o.ipp_verify_proof(n, g, hh, u, c, pr2)
+    assert o.ipp_generate_proof([], [], u, None, [], []) == dict(lCommits=[], rCommits=[], l=0, r=0)
+
+
+def test_log_base2_matches_double_arithmetic():
+    assert all(o.log_base2(2**k) == k for k in range(1, 257))
+    assert o.log_base2(2**64 + 1) == 64 and o.log_base2(2**64 - 1) == 64  # Double rounding, as in Haskell

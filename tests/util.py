@@ -1,0 +1,30 @@
+"""Shared helpers for the tests."""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def golden():
+    with open(os.path.join(HERE, "golden", "vectors.json")) as f:
+        return json.load(f)
+
+
+def ux(h):
+    return int(h, 16)
+
+
+def up(p):
+    return None if p is None else (int(p[0], 16), int(p[1], 16))
+
+
+def load_proof(pj):
+    return dict(tBlinding=ux(pj["tBlinding"]), mu=ux(pj["mu"]), t=ux(pj["t"]), aCommit=up(pj["aCommit"]),
+                sCommit=up(pj["sCommit"]), t1Commit=up(pj["t1Commit"]), t2Commit=up(pj["t2Commit"]),
+                productProof=dict(lCommits=[up(p) for p in pj["lCommits"]], rCommits=[up(p) for p in pj["rCommits"]],
+                                  l=ux(pj["l"]), r=ux(pj["r"])))
+
+
+def load_blinders(bj):
+    return ([ux(v) for v in bj["sL"]], [ux(v) for v in bj["sR"]], ux(bj["aBlinding"]), ux(bj["sBlinding"]),
+            ux(bj["t1Blinding"]), ux(bj["t2Blinding"]))
