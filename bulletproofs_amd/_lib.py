@@ -35,6 +35,15 @@ SYMBOLS = {
     "bp_msm": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
+    "bp_ctx_set_generators": (_int, [_vp, _u8p, _u8p, _u8p, ctypes.c_uint32]),
+    "bp_vbatch_create": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
+    "bp_vbatch_destroy": (None, [_vp]),
+    "bp_vbatch_rounds": (ctypes.c_uint32, [_vp]),
+    "bp_vbatch_point_rows": (ctypes.c_uint32, [_vp]),
+    "bp_vbatch_load": (_int, [_vp, _u8p, _u8p]),
+    "bp_vbatch_begin": (_int, [_vp, _u8p, _u8p]),
+    "bp_vbatch_round": (_int, [_vp, ctypes.c_uint32, _u8p, _u8p]),
+    "bp_vbatch_finish": (_int, [_vp, _u8p]),
 }
 
 
@@ -186,3 +195,52 @@ class Engine:
         out = ctypes.create_string_buffer(32 * n)
         self._check(self.lib.bp_field_op(self.h, field, op, enc_scalars(a), enc_scalars(b), n, out), "bp_field_op")
         return dec_scalars(out.raw, n)
+
+    # -- generators and the batch verifier state machine ---------------------------------
+    def set_generators(self, gs, hs, h):
+        """gs, hs: lists of points (`take n gs/hs`, Utils.hs:19-25), h: point."""
+        n = len(gs)
+        self._check(self.lib.bp_ctx_set_generators(self.h, enc_points(gs), enc_points(hs), enc_point(h), n),
+                    "bp_ctx_set_generators")
+
+    def vbatch(self, n_bits, m, batch):
+        return VBatch(self, n_bits, m, batch)
+
+
+class VBatch:
+    """bp_vbatch_* state machine: B proofs of one shape in lock-step; the caller
+    supplies the Fiat-Shamir challenges."""
+
+    def __init__(self, eng, n_bits, m, batch):
+        self.eng = eng
+        self.B = batch
+        h = ctypes.c_void_p()
+        eng._check(eng.lib.bp_vbatch_create(eng.h, n_bits, m, batch, ctypes.byref(h)), "bp_vbatch_create")
+        self.h = h
+        self.rounds = eng.lib.bp_vbatch_rounds(h)
+        self.point_rows = eng.lib.bp_vbatch_point_rows(h)
+
+    def close(self):
+        if self.h:
+            self.eng.lib.bp_vbatch_destroy(self.h)
+            self.h = None
+
+    def load(self, scalars, points):
+        """scalars: bytes 5*B*32 (rows tBlinding, mu, t, l, r); points: bytes rows*B*64."""
+        assert len(scalars) == 5 * self.B * 32 and len(points) == self.point_rows * self.B * 64
+        self.eng._check(self.eng.lib.bp_vbatch_load(self.h, scalars, points), "bp_vbatch_load")
+
+    def begin(self, challenges):
+        out = ctypes.create_string_buffer(64 * self.B)
+        self.eng._check(self.eng.lib.bp_vbatch_begin(self.h, challenges, out), "bp_vbatch_begin")
+        return out.raw
+
+    def round(self, r, x):
+        out = ctypes.create_string_buffer(64 * self.B)
+        self.eng._check(self.eng.lib.bp_vbatch_round(self.h, r, x, out), "bp_vbatch_round")
+        return out.raw
+
+    def finish(self):
+        out = ctypes.create_string_buffer(self.B)
+        self.eng._check(self.eng.lib.bp_vbatch_finish(self.h, out), "bp_vbatch_finish")
+        return [b != 0 for b in out.raw]

@@ -59,8 +59,11 @@ struct bp_ctx {
   bp::DevBuf vws;       // batch-verifier workspace
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
-  // generator state (filled by bp_ctx_set_generators)
-  uint32_t n_gens = 0;
+  // generator state (filled by bp_ctx_set_generators); pointers into `gen`
+  uint32_t n_gens = 0;       // generator pairs (gs_i, hs_i)
+  uint32_t n_bases = 0;      // rows of d_bases: gs, hs, G, H, GS_k
+  uint8_t* d_bases = nullptr;  // affine, 64 B each
+  uint8_t* d_table = nullptr;  // fixed-base window table, see fixedbase.h
 };
 
 #define BP_TRY(expr)                                                                          \

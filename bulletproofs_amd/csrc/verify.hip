@@ -1,0 +1,491 @@
+// Batched range-proof verification on gfx950: the EC and scalar-field work of
+//   MultiRangeProof.verifyProof      (/root/reference/Bulletproofs/MultiRangeProof/Verifier.hs:19-88)
+//   computeLRCommitment              (RangeProof/Internal.hs:169-206)
+//   InnerProductProof.verifyProof    (InnerProductProof/Verifier.hs:18-73)
+// for B independent proofs in lock-step.  Fiat-Shamir hashing stays on the host:
+// the host supplies y, z, x, uChallenge and, round by round, x_k computed from the
+// affine text of the running commitment this file returns (Verifier.hs:44-53).
+//
+// Per proof the verdict is  verifyTPoly && verifyLRCommitment  exactly: both are
+// group equations, evaluated here as
+//   E1 = sum_i (l s_i) G_i + sum_i (r s_{nm-1-i} y^-i) H_i + (l r u) G  -  acc_k   == O
+//   E2 = (t - delta) G + tau H - sum_j z^(j+2) V_j - x T1 - x^2 T2               == O
+// with acc_0 = P (computeLRCommitment) and acc_{k+1} = x_k^2 L_k + x_k^-2 R_k + acc_k.
+// hs' = y^-i hs_i is never materialised: y^-i is folded into the scalars.
+//
+// Data layout: every per-proof array is [field][proof] (proof fastest) so a wave
+// of 64 proofs reads and writes contiguous lines.
+#include "engine.h"
+#include "devio.h"
+#include "fixedbase.h"
+#include "verify.h"
+
+namespace bp {
+
+// ---- per-proof constants (Montgomery form), cst[c * B + p] -----------------------
+enum { C_Y = 0, C_Z, C_X, C_U, C_YINV, C_X2, C_DELTA, C_S0, C_COUNT };
+
+__device__ __forceinline__ u256 ldm(const u256* a, size_t idx) { return ld_u256(a + idx); }
+__device__ __forceinline__ void stm(u256* a, size_t idx, const u256& v) { st_u256(a + idx, v); }
+
+__device__ __forceinline__ void put_digits(uint32_t* dig, uint32_t term, uint32_t B, uint32_t p, const u256& k_canon) {
+  uint32_t d[FB_DWORDS];
+  fb_recode(k_canon, d);
+#pragma unroll
+  for (int g = 0; g < FB_DWORDS; g++) dig[((size_t)term * FB_DWORDS + g) * B + p] = d[g];
+}
+
+// thread per proof: challenges -> Montgomery constants, y^-i ladder, z powers, delta
+__global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restrict__ chal /*[4][B][32]*/,
+                                               u256* __restrict__ cst, u256* __restrict__ ypowinv /*[nm][B]*/,
+                                               u256* __restrict__ zpow /*[m+3][B]*/) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 y = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)0 * B + p) * 32)));
+  u256 z = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)1 * B + p) * 32)));
+  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)2 * B + p) * 32)));
+  u256 u = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)3 * B + p) * 32)));
+  u256 yinv = Fr::inv(y);
+  stm(cst, C_Y * B + p, y);
+  stm(cst, C_Z * B + p, z);
+  stm(cst, C_X * B + p, x);
+  stm(cst, C_U * B + p, u);
+  stm(cst, C_YINV * B + p, yinv);
+  stm(cst, C_X2 * B + p, Fr::sqr(x));
+  // y^-i and sum_i y^i, i < nm   (powerVector y nm; RangeProof/Internal.hs:154)
+  u256 cur = Fr::one(), ycur = Fr::one(), ysum = u256_zero();
+  for (uint32_t i = 0; i < d.nm; i++) {
+    stm(ypowinv, (size_t)i * B + p, cur);
+    cur = Fr::mul(cur, yinv);
+    // powerVector's 0^0 = 0 special case (Utils.hs:50-52) only matters for y = 0
+    ysum = Fr::add(ysum, ycur);
+    ycur = Fr::mul(ycur, y);
+  }
+  // z^e, e = 0..m+2
+  u256 zc = Fr::one();
+  for (uint32_t e = 0; e < d.m + 3; e++) {
+    stm(zpow, (size_t)e * B + p, zc);
+    zc = Fr::mul(zc, z);
+  }
+  // delta = (z - z^2) * sum y^i  -  sum_{j=1..m} z^(j+2) * (2^n - 1)
+  u256 z2 = Fr::sqr(z);
+  u256 two_n = u256_zero();
+  two_n.v[d.n >> 5] = 1u << (d.n & 31);  // n <= 255
+  u256 tn1 = Fr::sub(Fr::to_mont(Fr::reduce_once(two_n)), Fr::one());
+  u256 zs = u256_zero(), zj = Fr::mul(z2, z);  // z^3
+  for (uint32_t j = 0; j < d.m; j++) {
+    zs = Fr::add(zs, zj);
+    zj = Fr::mul(zj, z);
+  }
+  u256 delta = Fr::sub(Fr::mul(Fr::sub(z, z2), ysum), Fr::mul(zs, tn1));
+  stm(cst, C_DELTA * B + p, delta);
+}
+
+// thread per (i, p): digits of c_i = z + z^(i/n + 2) * 2^(i%n) * y^-i for base H_i;
+// i == 0 also emits the three single terms of P.
+__global__ void __launch_bounds__(256) k_vprep1(VDims d, const uint8_t* __restrict__ sc /*[5][B][32]*/,
+                                               const u256* __restrict__ cst, const u256* __restrict__ ypowinv,
+                                               const u256* __restrict__ zpow, uint32_t* __restrict__ dig) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t B = d.B;
+  if (t >= (size_t)d.nm * B) return;
+  uint32_t i = (uint32_t)(t / B), p = (uint32_t)(t % B);
+  u256 z = ldm(cst, C_Z * B + p);
+  uint32_t j = i / d.n, k = i % d.n;
+  u256 two_k = u256_zero();
+  two_k.v[k >> 5] = 1u << (k & 31);
+  u256 c = Fr::mul(Fr::mul(ldm(zpow, (size_t)(j + 2) * B + p), Fr::to_mont(Fr::reduce_once(two_k))),
+                   ldm(ypowinv, (size_t)i * B + p));
+  c = Fr::add(c, z);
+  put_digits(dig, i, d.B, p, Fr::from_mont(c));
+  if (i == 0) {
+    u256 mu = Fr::reduce_once(ld_u256(sc + ((size_t)1 * B + p) * 32));
+    u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
+    put_digits(dig, d.nm + 0, d.B, p, Fr::from_mont(Fr::neg(z)));                         // -z  * GS
+    put_digits(dig, d.nm + 1, d.B, p, Fr::neg(mu));                                       // -mu * H  (canonical neg)
+    put_digits(dig, d.nm + 2, d.B, p, Fr::from_mont(Fr::mul(tt, ldm(cst, C_U * B + p))));  // t*u * G
+  }
+}
+
+// ---- fixed-base multi-exponentiation: acc[p] = sum_terms k[term][p] * base(term) ---------
+// lpp lanes cooperate on one proof (terms strided over them) and are summed by shuffles.
+__global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nterms, uint32_t lpp,
+                                                       const uint32_t* __restrict__ dig,
+                                                       const uint32_t* __restrict__ term_base,
+                                                       const uint8_t* __restrict__ table, xyzz* __restrict__ acc_out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t p = t / lpp, sub = t % lpp;
+  bool live = p < B;
+  xyzz acc = xyzz_inf();
+  if (live) {
+    for (uint32_t term = sub; term < nterms; term += lpp) {
+      const uint8_t* rows = table + (size_t)term_base[term] * FB_WINDOWS * FB_ENTRIES * 64;
+      for (int g = 0; g < FB_DWORDS; g++) {
+        uint32_t word = dig[((size_t)term * FB_DWORDS + g) * B + p];
+        if (word == 0) continue;
+        for (int b = 0; b < 4; b++) {
+          uint32_t code = (word >> (8 * b)) & 0xFFu;
+          if (code == 0) continue;
+          int w = 4 * g + b;
+          bool neg = code > 0x80u;
+          uint32_t mag = neg ? 256u - code : code;
+          affine q = ld_affine(rows + ((size_t)w * FB_ENTRIES + (mag - 1)) * 64);
+          bucket_add(acc, q, neg);
+        }
+      }
+    }
+  }
+  for (uint32_t dlt = lpp >> 1; dlt > 0; dlt >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, dlt);
+    acc = xyzz_add(acc, o);
+  }
+  if (live && sub == 0) st_xyzz(&acc_out[p], acc);
+}
+
+// ---- variable-base terms: bit-serial interleaved double-and-add ------------------------------
+// result = [acc_in] + sum_{j<nt} k_j * P_j + sum_{j<na} (+/-) Q_j
+template <int NT>
+__device__ __forceinline__ xyzz var_multiexp(const u256 k[NT], const affine P[NT]) {
+  u256 kk[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) kk[j] = k[j];
+  xyzz acc = xyzz_inf();
+  for (int bit = 0; bit < 256; bit++) {
+    acc = xyzz_dbl(acc);
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      uint32_t top = kk[j].v[7] >> 31;
+#pragma unroll
+      for (int i = 7; i > 0; i--) kk[j].v[i] = (kk[j].v[i] << 1) | (kk[j].v[i - 1] >> 31);
+      kk[j].v[0] <<= 1;
+      if (top) acc = xyzz_madd(acc, P[j]);
+    }
+  }
+  return acc;
+}
+
+// stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported)
+__global__ void __launch_bounds__(256) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
+                                                    const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
+                                                    uint8_t* __restrict__ acc_aff /*[B][64]*/) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 k[1] = {Fr::from_mont(ldm(cst, C_X * B + p))};
+  affine P[1] = {ld_affine(pts + ((size_t)VP_S * B + p) * 64)};
+  xyzz acc = var_multiexp<1>(k, P);
+  acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
+  acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
+  st_affine(acc_aff + (size_t)p * 64, xyzz_to_affine(acc));
+}
+
+// one IPP round of mkChallenges: acc <- x^2 L + x^-2 R + acc  (Verifier.hs:47-50)
+__global__ void __launch_bounds__(256) k_round(VDims d, uint32_t round, const uint8_t* __restrict__ pts,
+                                              const uint8_t* __restrict__ xk /*[B][32] canonical*/,
+                                              u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
+                                              uint8_t* __restrict__ acc_aff) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
+  u256 xinv = Fr::inv(x);
+  stm(xk_m, (size_t)round * B + p, x);
+  stm(xkinv_m, (size_t)round * B + p, xinv);
+  u256 k[2] = {Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv))};
+  affine P[2] = {ld_affine(pts + ((size_t)(VP_L0 + round) * B + p) * 64),
+                 ld_affine(pts + ((size_t)(VP_L0 + d.k + round) * B + p) * 64)};
+  xyzz acc = var_multiexp<2>(k, P);
+  acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
+  st_affine(acc_aff + (size_t)p * 64, xyzz_to_affine(acc));
+}
+
+// thread per proof: s0 = prod_k x_k^-1  (mkOtherExponents, Verifier.hs:59)
+__global__ void __launch_bounds__(256) k_vprep3a(VDims d, const u256* __restrict__ xkinv_m, u256* __restrict__ cst) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 s0 = Fr::one();
+  for (uint32_t r = 0; r < d.k; r++) s0 = Fr::mul(s0, ldm(xkinv_m, (size_t)r * B + p));
+  stm(cst, C_S0 * B + p, s0);
+}
+
+// thread per (i, p): s_i = s0 * prod_{bit j of i} x_{k-1-j}^2   (Verifier.hs:55-73: challenges are
+// listed last round first, so bit 0 pairs with the LAST round); emits
+//   term i            (base G_i):        l * s_i
+//   term nm + (nm-1-i) (base H_{nm-1-i}): r * s_i * y^-(nm-1-i)        (reverse otherExponents, :38)
+// and for i == 0 the remaining single terms and the variable-base scalars of E2.
+__global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restrict__ sc, const u256* __restrict__ cst,
+                                               const u256* __restrict__ ypowinv, const u256* __restrict__ zpow,
+                                               const u256* __restrict__ xk_m, uint32_t* __restrict__ dig_a,
+                                               uint32_t* __restrict__ dig_b, uint8_t* __restrict__ vs /*[m+2][B][32]*/) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t B = d.B;
+  if (t >= (size_t)d.nm * B) return;
+  uint32_t i = (uint32_t)(t / B), p = (uint32_t)(t % B);
+  u256 s = ldm(cst, C_S0 * B + p);
+  for (uint32_t j = 0; j < d.k; j++)
+    if ((i >> j) & 1u) s = Fr::mul(s, Fr::sqr(ldm(xk_m, (size_t)(d.k - 1 - j) * B + p)));
+  u256 l = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)3 * B + p) * 32)));
+  u256 r = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)4 * B + p) * 32)));
+  put_digits(dig_a, i, d.B, p, Fr::from_mont(Fr::mul(l, s)));
+  uint32_t hi = d.nm - 1 - i;
+  put_digits(dig_a, d.nm + hi, d.B, p, Fr::from_mont(Fr::mul(Fr::mul(r, s), ldm(ypowinv, (size_t)hi * B + p))));
+  if (i == 0) {
+    u256 u = ldm(cst, C_U * B + p);
+    put_digits(dig_a, 2 * d.nm, d.B, p, Fr::from_mont(Fr::mul(Fr::mul(l, r), u)));  // (l r u) G
+    u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
+    u256 tau = Fr::reduce_once(ld_u256(sc + ((size_t)0 * B + p) * 32));
+    put_digits(dig_b, 0, d.B, p, Fr::from_mont(Fr::sub(tt, ldm(cst, C_DELTA * B + p))));  // (t - delta) G
+    put_digits(dig_b, 1, d.B, p, tau);                                                    // tau H
+    for (uint32_t j = 0; j < d.m; j++)
+      st_u256(vs + ((size_t)j * B + p) * 32, Fr::from_mont(Fr::neg(ldm(zpow, (size_t)(j + 2) * B + p))));
+    st_u256(vs + ((size_t)d.m * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X * B + p))));
+    st_u256(vs + ((size_t)(d.m + 1) * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X2 * B + p))));
+  }
+}
+
+// acc2 += sum of up to 2 variable-base terms per pass (terms j0, j0+1 of the E2 list:
+// V_0..V_{m-1}, T1, T2); the list length m + 2 is even for every power-of-two m >= 2 and 3 for m = 1.
+template <int NT>
+__global__ void __launch_bounds__(256) k_var_terms(VDims d, uint32_t j0, const uint8_t* __restrict__ pts,
+                                                  const uint8_t* __restrict__ vs, xyzz* __restrict__ acc2) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 k[NT];
+  affine P[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    uint32_t term = j0 + j;
+    k[j] = ld_u256(vs + ((size_t)term * B + p) * 32);
+    // point row: V_j for term < m, then T1, T2
+    uint32_t row = term < d.m ? VP_L0 + 2 * d.k + term : (term == d.m ? VP_T1 : VP_T2);
+    P[j] = ld_affine(pts + ((size_t)row * B + p) * 64);
+  }
+  xyzz acc = var_multiexp<NT>(k, P);
+  acc = xyzz_add(acc, ld_xyzz(&acc2[p]));
+  st_xyzz(&acc2[p], acc);
+}
+
+// verdict[p] = (acc1 == acc_k) && (acc2 == O)
+__global__ void __launch_bounds__(256) k_verdict(VDims d, const xyzz* __restrict__ acc1, const xyzz* __restrict__ acc2,
+                                                const uint8_t* __restrict__ acc_aff, uint8_t* __restrict__ verdict) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  xyzz e1 = xyzz_madd(ld_xyzz(&acc1[p]), affine_neg(ld_affine(acc_aff + (size_t)p * 64)));
+  bool ok = xyzz_is_inf(e1) && xyzz_is_inf(ld_xyzz(&acc2[p]));
+  verdict[p] = ok ? 1 : 0;
+}
+
+}  // namespace bp
+
+using namespace bp;
+
+// ------------------------------------------------------------------------------------------------
+struct bp_vbatch {
+  bp_ctx* ctx;
+  VDims d;
+  DevBuf buf;
+  // device
+  uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
+  u256 *cst, *ypowinv, *zpow, *xk_m, *xkinv_m;
+  uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
+  xyzz *acc1, *acc2;
+  uint32_t nt1, nt3a, nt3b, npts;
+  int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
+};
+
+#define VB_GRID(n) dim3((unsigned)((((size_t)(n)) + 255) / 256)), dim3(256), 0, ctx->stream
+
+extern "C" {
+
+int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, bp_vbatch** out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(out, "null pointer");
+  *out = nullptr;
+  BP_REQUIRE(n_bits >= 1 && n_bits <= 128 && (n_bits & (n_bits - 1)) == 0, "n_bits must be a power of two <= 128");
+  BP_REQUIRE(m >= 1 && (m & (m - 1)) == 0, "m must be a power of two (pad commitments with O, Verifier.hs:37-38)");
+  BP_REQUIRE(batch >= 1 && batch <= (1u << 22), "batch must be in 1..2^22");
+  uint32_t nm = n_bits * m;
+  if (ctx->n_gens == 0) {
+    ctx->err = "generators not set (bp_ctx_set_generators)";
+    return BP_ERR_STATE;
+  }
+  BP_REQUIRE(nm <= ctx->n_gens, "n_bits * m exceeds the generator count of the context");
+  BP_TRY(hipSetDevice(ctx->device));
+  bp_vbatch* vb = new bp_vbatch();
+  vb->ctx = ctx;
+  VDims& d = vb->d;
+  d.B = batch;
+  d.n = n_bits;
+  d.m = m;
+  d.nm = nm;
+  d.k = 0;
+  while ((1u << d.k) < nm) d.k++;
+  vb->npts = VP_L0 + 2 * d.k + m;
+  vb->nt1 = nm + 3;
+  vb->nt3a = 2 * nm + 1;
+  vb->nt3b = 2;
+  size_t B = batch;
+  auto carve = [&](void* base) {
+    Carver c(base);
+    vb->sc = c.take<uint8_t>(5 * B * 32);
+    vb->pts = c.take<uint8_t>((size_t)vb->npts * B * 64);
+    vb->chal = c.take<uint8_t>(4 * B * 32);
+    vb->xk = c.take<uint8_t>(B * 32);
+    vb->acc_aff = c.take<uint8_t>(B * 64);
+    vb->vs = c.take<uint8_t>((size_t)(m + 2) * B * 32);
+    vb->verdict = c.take<uint8_t>(B);
+    vb->cst = c.take<u256>((size_t)C_COUNT * B);
+    vb->ypowinv = c.take<u256>((size_t)nm * B);
+    vb->zpow = c.take<u256>((size_t)(m + 3) * B);
+    vb->xk_m = c.take<u256>((size_t)(d.k ? d.k : 1) * B);
+    vb->xkinv_m = c.take<u256>((size_t)(d.k ? d.k : 1) * B);
+    vb->dig1 = c.take<uint32_t>((size_t)vb->nt1 * FB_DWORDS * B);
+    vb->dig3a = c.take<uint32_t>((size_t)vb->nt3a * FB_DWORDS * B);
+    vb->dig3b = c.take<uint32_t>((size_t)vb->nt3b * FB_DWORDS * B);
+    vb->tb1 = c.take<uint32_t>(vb->nt1);
+    vb->tb3a = c.take<uint32_t>(vb->nt3a);
+    vb->tb3b = c.take<uint32_t>(vb->nt3b);
+    vb->acc1 = c.take<xyzz>(B);
+    vb->acc2 = c.take<xyzz>(B);
+    return c.off;
+  };
+  size_t need = carve(nullptr);
+  if (vb->buf.reserve(need) != 0) {
+    delete vb;
+    ctx->err = "verifier workspace allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  carve(vb->buf.p);
+  // term -> base maps
+  uint32_t ng = ctx->n_gens;
+  std::vector<uint32_t> tb1(vb->nt1), tb3a(vb->nt3a), tb3b(2);
+  for (uint32_t i = 0; i < nm; i++) tb1[i] = fb_base_h(ng, i);
+  tb1[nm] = fb_base_gsum(ng, d.k);
+  tb1[nm + 1] = fb_base_H(ng);
+  tb1[nm + 2] = fb_base_G(ng);
+  for (uint32_t i = 0; i < nm; i++) {
+    tb3a[i] = fb_base_g(i);
+    tb3a[nm + i] = fb_base_h(ng, i);
+  }
+  tb3a[2 * nm] = fb_base_G(ng);
+  tb3b[0] = fb_base_G(ng);
+  tb3b[1] = fb_base_H(ng);
+  hipError_t e = hipMemcpyAsync(vb->tb1, tb1.data(), tb1.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(vb->tb3a, tb3a.data(), tb3a.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(vb->tb3b, tb3b.data(), tb3b.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    vb->buf.release();
+    delete vb;
+    ctx->err = std::string("bp_vbatch_create: ") + hipGetErrorString(e);
+    return BP_ERR_DEVICE;
+  }
+  vb->stage = 0;
+  *out = vb;
+  return BP_OK;
+}
+
+void bp_vbatch_destroy(bp_vbatch* vb) {
+  if (!vb) return;
+  (void)hipSetDevice(vb->ctx->device);
+  (void)hipStreamSynchronize(vb->ctx->stream);
+  vb->buf.release();
+  delete vb;
+}
+
+uint32_t bp_vbatch_rounds(const bp_vbatch* vb) { return vb ? vb->d.k : 0; }
+uint32_t bp_vbatch_point_rows(const bp_vbatch* vb) { return vb ? vb->npts : 0; }
+
+int bp_vbatch_load(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
+  if (!vb) return BP_ERR_ARG;
+  bp_ctx* ctx = vb->ctx;
+  BP_REQUIRE(scalars && points, "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  size_t B = vb->d.B;
+  BP_TRY(hipMemcpyAsync(vb->sc, scalars, 5 * B * 32, hipMemcpyHostToDevice, ctx->stream));
+  BP_TRY(hipMemcpyAsync(vb->pts, points, (size_t)vb->npts * B * 64, hipMemcpyHostToDevice, ctx->stream));
+  vb->stage = 1;
+  return BP_OK;
+}
+
+int bp_vbatch_begin(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment) {
+  if (!vb) return BP_ERR_ARG;
+  bp_ctx* ctx = vb->ctx;
+  BP_REQUIRE(challenges && out_commitment, "null pointer");
+  if (vb->stage < 1) {
+    ctx->err = "bp_vbatch_begin before bp_vbatch_load";
+    return BP_ERR_STATE;
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  VDims d = vb->d;
+  size_t B = d.B;
+  BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow);
+  hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
+  uint32_t lpp = vbatch_lpp(d.B);
+  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt1, lpp, vb->dig1, vb->tb1, ctx->d_table, vb->acc1);
+  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->acc_aff);
+  BP_TRY(hipGetLastError());
+  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, ctx->stream));
+  BP_TRY(hipStreamSynchronize(ctx->stream));
+  vb->stage = 2;
+  return BP_OK;
+}
+
+int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment) {
+  if (!vb) return BP_ERR_ARG;
+  bp_ctx* ctx = vb->ctx;
+  BP_REQUIRE(x && out_commitment, "null pointer");
+  if (vb->stage != (int)(2 + round) || round >= vb->d.k) {
+    ctx->err = "bp_vbatch_round out of order";
+    return BP_ERR_STATE;
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  VDims d = vb->d;
+  size_t B = d.B;
+  BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->acc_aff);
+  BP_TRY(hipGetLastError());
+  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, ctx->stream));
+  BP_TRY(hipStreamSynchronize(ctx->stream));
+  vb->stage++;
+  return BP_OK;
+}
+
+int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts) {
+  if (!vb) return BP_ERR_ARG;
+  bp_ctx* ctx = vb->ctx;
+  BP_REQUIRE(verdicts, "null pointer");
+  if (vb->stage != (int)(2 + vb->d.k)) {
+    ctx->err = "bp_vbatch_finish before all rounds";
+    return BP_ERR_STATE;
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  VDims d = vb->d;
+  size_t B = d.B;
+  hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xkinv_m, vb->cst);
+  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->xk_m,
+                     vb->dig3a, vb->dig3b, vb->vs);
+  uint32_t lpp = vbatch_lpp(d.B);
+  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt3a, lpp, vb->dig3a, vb->tb3a, ctx->d_table,
+                     vb->acc1);
+  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B), d.B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, ctx->d_table, vb->acc2);
+  uint32_t nv = d.m + 2;
+  uint32_t j = 0;
+  if (nv & 1u) {  // m = 1: three terms, one pass of three
+    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID(B), d, 0u, vb->pts, vb->vs, vb->acc2);
+    j = 3;
+  }
+  for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->acc2);
+  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict);
+  BP_TRY(hipGetLastError());
+  BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, ctx->stream));
+  BP_TRY(hipStreamSynchronize(ctx->stream));
+  vb->stage = 1;  // may be begun again with the same loaded proofs
+  return BP_OK;
+}
+
+}  // extern "C"

@@ -90,6 +90,51 @@ int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok)
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
 int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
 
+/* ---- generator set ----
+ *
+ * bp_ctx_set_generators  uploads the reference's generator lists and builds the
+ *                   device-resident fixed-base tables.  gs, hs: n_gens affine
+ *                   points each (`take n gs`, `take n hs`; Bulletproofs/Utils.hs:19-25),
+ *                   h: one point (Utils.hs:14-15); `gen` is built in.  n_gens is a
+ *                   power of two in 1..8192 and bounds n*m of every later proof.
+ *                   The lists are CAFs in the reference (evaluated once per
+ *                   process); here they are evaluated once per context.
+ */
+int bp_ctx_set_generators(bp_ctx* ctx, const uint8_t* gs, const uint8_t* hs, const uint8_t* h, uint32_t n_gens);
+
+/* ---- batched range-proof verification, lock-step state machine ----
+ *
+ * Verifies `batch` independent proofs of one shape (n_bits, m) with the
+ * Fiat-Shamir transcript kept on the host: the caller hashes, this engine does
+ * the scalar-field and curve work of
+ *   MultiRangeProof.verifyProof   (Bulletproofs/MultiRangeProof/Verifier.hs:19-88),
+ *   computeLRCommitment           (Bulletproofs/RangeProof/Internal.hs:169-206),
+ *   InnerProductProof.verifyProof (Bulletproofs/InnerProductProof/Verifier.hs:18-73).
+ * All arrays are structure-of-arrays: row r of an array holds that field for
+ * proofs 0..batch-1 consecutively.
+ *
+ *   bp_vbatch_create   n_bits = log2(upperBound) (power of two <= 128), m = number of
+ *                      commitments after padding to a power of two (Verifier.hs:37-38)
+ *   bp_vbatch_load     scalars: 5 rows x 32 B: tBlinding, mu, t, l, r
+ *                      points : (4 + 2k + m) rows x 64 B: aCommit, sCommit, t1Commit,
+ *                      t2Commit, lCommits[0..k), rCommits[0..k), vCommits[0..m), k = log2(n_bits*m)
+ *   bp_vbatch_begin    challenges: 4 rows x 32 B: y, z, x (shamirY/Z/X, Utils.hs:145-165) and
+ *                      uChallenge (shamirU, Utils.hs:172-174); returns the commitment
+ *                      P = computeLRCommitment(...) per proof (64 B affine each)
+ *   bp_vbatch_round    round r = 0..k-1 of mkChallenges (Verifier.hs:44-53): x = shamirX'(acc, L_r, R_r)
+ *                      per proof; returns acc' = x^2 L_r + x^-2 R_r + acc per proof
+ *   bp_vbatch_finish   verdicts[i] = 1 iff verifyTPoly && verifyLRCommitment hold for proof i
+ */
+typedef struct bp_vbatch bp_vbatch;
+int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, bp_vbatch** out);
+void bp_vbatch_destroy(bp_vbatch* vb);
+uint32_t bp_vbatch_rounds(const bp_vbatch* vb);
+uint32_t bp_vbatch_point_rows(const bp_vbatch* vb);
+int bp_vbatch_load(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points);
+int bp_vbatch_begin(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment);
+int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment);
+int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts);
+
 /* ---- field arithmetic self-test hooks (used by the parity tests) ----
  * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a)
  * field: 0 = Fq (base field, pseudo-Mersenne path), 1 = Fr (Montgomery path),

@@ -1,0 +1,128 @@
+"""GPU parity tests for the batch verifier state machine (bp_vbatch_*), with the
+Fiat-Shamir hashing done by the oracle's transcript functions: every
+intermediate the reference exposes (computeLRCommitment, the mkChallenges
+accumulator of each round) and the final Bool are compared bit for bit."""
+import random
+
+import pytest
+
+import bp_oracle as o
+from bulletproofs_amd import _lib
+from util import golden, up, load_proof
+
+pytestmark = pytest.mark.gpu
+R = o.R
+
+
+@pytest.fixture(scope="module")
+def eng_gens(engine):
+    engine.set_generators(o.gs(128), o.hs(128), o.h())
+    return engine
+
+
+def pack_batch(proofs, vcommits, m2):
+    """SoA byte arrays for bp_vbatch_load."""
+    B = len(proofs)
+    k = len(proofs[0]["productProof"]["lCommits"])
+    sc = b"".join(b"".join(_lib.enc_scalar(f(pr)) for pr in proofs) for f in (
+        lambda p: p["tBlinding"], lambda p: p["mu"], lambda p: p["t"],
+        lambda p: p["productProof"]["l"], lambda p: p["productProof"]["r"]))
+    rows = [[pr["aCommit"] for pr in proofs], [pr["sCommit"] for pr in proofs],
+            [pr["t1Commit"] for pr in proofs], [pr["t2Commit"] for pr in proofs]]
+    rows += [[pr["productProof"]["lCommits"][r] for pr in proofs] for r in range(k)]
+    rows += [[pr["productProof"]["rCommits"][r] for pr in proofs] for r in range(k)]
+    for j in range(m2):
+        rows.append([(vc[j] if j < len(vc) else None) for vc in vcommits])
+    pts = b"".join(_lib.enc_points(row) for row in rows)
+    assert len(sc) == 5 * B * 32
+    return sc, pts, k
+
+
+def run_batch(eng, n, m2, proofs, vcommits, check_trace=True):
+    B = len(proofs)
+    sc, pts, k = pack_batch(proofs, vcommits, m2)
+    vb = eng.vbatch(n, m2, B)
+    assert vb.rounds == k
+    vb.load(sc, pts)
+    ys = [o.shamir_y(p["aCommit"], p["sCommit"]) for p in proofs]
+    zs = [o.shamir_z(p["aCommit"], p["sCommit"], y) for p, y in zip(proofs, ys)]
+    xs = [o.shamir_x(p["aCommit"], p["sCommit"], p["t1Commit"], p["t2Commit"], y, z)
+          for p, y, z in zip(proofs, ys, zs)]
+    us = [o.shamir_u(p["tBlinding"], p["mu"], p["t"]) for p in proofs]
+    chal = _lib.enc_scalars(ys) + _lib.enc_scalars(zs) + _lib.enc_scalars(xs) + _lib.enc_scalars(us)
+    acc = _lib.dec_points(vb.begin(chal), B)
+    if check_trace:
+        for i, p in enumerate(proofs):
+            hsp = o.hs_prime(ys[i], n * m2)
+            exp = o.compute_lr_commitment(n, m2, p["aCommit"], p["sCommit"], p["t"], p["tBlinding"], p["mu"],
+                                          xs[i], ys[i], zs[i], hsp)
+            assert acc[i] == exp, "computeLRCommitment mismatch for proof %d" % i
+    for r in range(k):
+        xk = [o.shamir_x_prime(acc[i], p["productProof"]["lCommits"][r], p["productProof"]["rCommits"][r])
+              for i, p in enumerate(proofs)]
+        new = _lib.dec_points(vb.round(r, _lib.enc_scalars(xk)), B)
+        if check_trace:
+            for i, p in enumerate(proofs):
+                li, ri = p["productProof"]["lCommits"][r], p["productProof"]["rCommits"][r]
+                xi = pow(xk[i], -1, R)
+                exp = o.point_add(o.point_add(o.point_mul(li, xk[i] * xk[i] % R), o.point_mul(ri, xi * xi % R)), acc[i])
+                assert new[i] == exp, "mkChallenges accumulator mismatch, proof %d round %d" % (i, r)
+        acc = new
+    verdicts = vb.finish()
+    vb.close()
+    return verdicts
+
+
+def mutate(rng, pr, vcs):
+    """Corruptions in the spirit of test/Test/Protocol/RangeProof.hs:183-194 and SURVEY 8d config 4."""
+    pr = dict(pr, productProof=dict(pr["productProof"]))
+    kind = rng.randrange(6)
+    if kind == 0:
+        pr["t"] = (pr["t"] + 1) % R
+    elif kind == 1 and pr["productProof"]["lCommits"]:
+        ipp = pr["productProof"]
+        ipp["lCommits"], ipp["rCommits"] = list(ipp["rCommits"]), list(ipp["lCommits"])
+    elif kind == 2:
+        vcs = [o.point_add(vcs[0], o.GEN)] + list(vcs[1:])  # commit (v+1) r
+    elif kind == 3:
+        pr["productProof"]["l"] = (pr["productProof"]["l"] + 1) % R
+    elif kind == 4:
+        pr["mu"] = (pr["mu"] + 5) % R
+    else:
+        pr["tBlinding"] = (pr["tBlinding"] + 1) % R
+    return pr, vcs
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 1), (8, 1), (4, 2), (8, 3), (16, 4)])
+def test_state_machine_vs_oracle(eng_gens, n, m):
+    rng = random.Random(1000 + 10 * n + m)
+    m2 = 2 ** o.log2_ceil(m)
+    proofs, vcs = [], []
+    for _ in range(3):
+        vs = [(rng.randrange(0, 2**n), rng.randrange(1, R)) for _ in range(m)]
+        pr = o.mrp_generate_proof(2**n, vs, *o.draw_blinders(rng, n * m2))
+        proofs.append(pr)
+        vcs.append([o.commit(v, b) for v, b in vs])
+    # honest + mutated copies in one batch: verdicts are per proof
+    bad = [mutate(rng, proofs[i % 3], vcs[i % 3]) for i in range(5)]
+    all_p = proofs + [b[0] for b in bad]
+    all_v = vcs + [b[1] for b in bad]
+    got = run_batch(eng_gens, n, m2, all_p, all_v)
+    exp = [o.mrp_verify_proof(2**n, v, p) for p, v in zip(all_p, all_v)]
+    assert exp[:3] == [True] * 3
+    assert got == exp
+
+
+def test_bench_proof_golden(eng_gens):
+    """The reference's bench input (bench/Bench/RangeProof.hs:10-14), n = 64."""
+    b = golden()["bench_proof"]
+    pr = load_proof(b["proof"])
+    vc = up(b["vCommit"])
+    rng = random.Random(5)
+    batch_p = [pr] * 3 + [mutate(rng, pr, [vc])[0] for _ in range(3)]
+    batch_v = [[vc]] * 6
+    got = run_batch(eng_gens, 64, 1, batch_p, batch_v, check_trace=False)
+    assert got[:3] == [True] * 3
+    assert got[3:] == [o.rp_verify_proof(2**64, vc, p) for p in batch_p[3:]]
+    # commitment to v+1 must not verify (RangeProof.hs:183-194)
+    assert run_batch(eng_gens, 64, 1, [pr], [[o.commit(b["v"] + 1, b["vBlinding"])]], check_trace=False) == [False]
