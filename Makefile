@@ -9,7 +9,7 @@ HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HIP_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
 HEADERS  := $(wildcard $(CSRC)/*.h) include/bpgpu.h
 
-all: bulletproofs_amd/libbpgpu.so tests/hostsim/libhostsim.so oracle
+all: bulletproofs_amd/libbpgpu.so tests/hostsim/libhostsim.so benchmarks/libbpbench.so oracle
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HEADERS)
 	@mkdir -p $(OBJDIR)
@@ -21,6 +21,9 @@ bulletproofs_amd/libbpgpu.so: $(HIP_OBJS)
 tests/hostsim/libhostsim.so: tests/hostsim/hostsim.cpp $(HEADERS)
 	g++ -O2 -std=c++17 -shared -fPIC -o $@ $<
 
+benchmarks/libbpbench.so: benchmarks/proofgen.hip bulletproofs_amd/libbpgpu.so $(HEADERS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $< -Lbulletproofs_amd -lbpgpu -Wl,-rpath,'$$ORIGIN/../bulletproofs_amd'
+
 benchmarks/microbench: benchmarks/microbench.hip $(HEADERS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -o $@ $<
 
@@ -28,6 +31,6 @@ oracle:
 	@if [ -f oracle/Makefile ]; then $(MAKE) -C oracle; fi
 
 clean:
-	rm -rf $(OBJDIR) bulletproofs_amd/libbpgpu.so tests/hostsim/libhostsim.so benchmarks/microbench
+	rm -rf $(OBJDIR) bulletproofs_amd/libbpgpu.so tests/hostsim/libhostsim.so benchmarks/microbench benchmarks/libbpbench.so
 
 .PHONY: all clean oracle

@@ -27,6 +27,9 @@ SYMBOLS = {
     "bp_last_error": (ctypes.c_char_p, [_vp]),
     "bp_ctx_sync": (_int, [_vp]),
     "bp_ctx_stream": (_vp, [_vp]),
+    "bp_ctx_profile": (_int, [_vp, _int]),
+    "bp_ctx_profile_read": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                                   ctypes.POINTER(ctypes.c_double)]),
     "bp_point_mul": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_point_add": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_point_neg": (_int, [_vp, _u8p, _sz, _u8p]),
@@ -44,6 +47,17 @@ SYMBOLS = {
     "bp_vbatch_begin": (_int, [_vp, _u8p, _u8p]),
     "bp_vbatch_round": (_int, [_vp, ctypes.c_uint32, _u8p, _u8p]),
     "bp_vbatch_finish": (_int, [_vp, _u8p]),
+    "bp_ctx_set_show_style": (_int, [_vp, _int]),
+    "bp_ctx_set_sqrt_branch": (_int, [_vp, _int]),
+    "bp_generators_derive": (_int, [_vp, ctypes.c_uint32, _u8p, _u8p, _u8p]),
+    "bp_log_base2": (_int, [_u8p, _sz]),
+    "bp_transcript": (_int, [_int, _int, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bp_rangeproof_verify_batch": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _u8p, _u8p, _u8p]),
+    "bp_vjob_create": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _int,
+                              ctypes.POINTER(_vp)]),
+    "bp_vjob_destroy": (None, [_vp]),
+    "bp_vjob_load": (_int, [_vp, _u8p, _u8p]),
+    "bp_vjob_run": (_int, [_vp, _u8p]),
 }
 
 
@@ -137,6 +151,16 @@ class Engine:
         if rc != 0:
             raise BpError("%s failed (%d): %s" % (what, rc, self.lib.bp_last_error(self.h).decode()))
 
+    def profile(self, enable=True):
+        self._check(self.lib.bp_ctx_profile(self.h, 1 if enable else 0), "bp_ctx_profile")
+
+    def profile_read(self, kernel):
+        """-> (total_ms, launches, mixed_adds) for kernel 0 (k_fixed_multiexp) or 1 (k_light)."""
+        ms, n, madds = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()
+        self._check(self.lib.bp_ctx_profile_read(self.h, kernel, ctypes.byref(ms), ctypes.byref(n),
+                                                 ctypes.byref(madds)), "bp_ctx_profile_read")
+        return ms.value, n.value, madds.value
+
     def sync(self):
         self._check(self.lib.bp_ctx_sync(self.h), "bp_ctx_sync")
 
@@ -205,6 +229,65 @@ class Engine:
 
     def vbatch(self, n_bits, m, batch):
         return VBatch(self, n_bits, m, batch)
+
+    def derive_generators(self, n):
+        """`h`, `take n gs`, `take n hs` (Utils.hs:14-25) evaluated by the engine and installed."""
+        g = ctypes.create_string_buffer(64 * n)
+        hh = ctypes.create_string_buffer(64 * n)
+        h1 = ctypes.create_string_buffer(64)
+        self._check(self.lib.bp_generators_derive(self.h, n, g, hh, h1), "bp_generators_derive")
+        return dec_points(g.raw, n), dec_points(hh.raw, n), dec_point(h1.raw)
+
+    def verify_batch(self, n_bits, m, batch, scalars, points):
+        """`map (verifyProof upperBound)` over a batch (MultiRangeProof/Verifier.hs:19-39)."""
+        out = ctypes.create_string_buffer(batch)
+        self._check(self.lib.bp_rangeproof_verify_batch(self.h, n_bits, m, batch, scalars, points, out),
+                    "bp_rangeproof_verify_batch")
+        return [b != 0 for b in out.raw]
+
+    def vjob(self, n_bits, m, batch, n_chunks=0, host_threads=0):
+        return VJob(self, n_bits, m, batch, n_chunks, host_threads)
+
+
+def transcript(style, which, pts=(), scs=(), raw=b""):
+    """bp_transcript: the reference's shamir*/oracle functions as the host layer computes them."""
+    lib = load_library()
+    out = ctypes.create_string_buffer(32)
+    rc = lib.bp_transcript(style, which, enc_points(pts), enc_scalars(scs), raw, len(raw), out)
+    if rc != 0:
+        raise BpError("bp_transcript failed: %d" % rc)
+    return dec_scalar(out.raw)
+
+
+def log_base2(upper_bound):
+    lib = load_library()
+    nbytes = max(1, (upper_bound.bit_length() + 7) // 8)
+    return lib.bp_log_base2(upper_bound.to_bytes(nbytes, "little"), nbytes)
+
+
+class VJob:
+    """bp_vjob_*: create / load (untimed) / run (timed) batch verification."""
+
+    def __init__(self, eng, n_bits, m, batch, n_chunks, host_threads):
+        self.eng = eng
+        self.B = batch
+        h = ctypes.c_void_p()
+        eng._check(eng.lib.bp_vjob_create(eng.h, n_bits, m, batch, n_chunks, host_threads, ctypes.byref(h)),
+                   "bp_vjob_create")
+        self.h = h
+
+    def load(self, scalars, points):
+        self.eng._check(self.eng.lib.bp_vjob_load(self.h, scalars, points), "bp_vjob_load")
+
+    def run(self):
+        out = ctypes.create_string_buffer(self.B)
+        self.eng._check(self.eng.lib.bp_vjob_run(self.h, out), "bp_vjob_run")
+        return out.raw
+
+    def close(self):
+        if self.h:
+            self.eng.lib.bp_vjob_destroy(self.h)
+            self.h = None
 
 
 class VBatch:

@@ -64,6 +64,16 @@ struct bp_ctx {
   uint32_t n_bases = 0;      // rows of d_bases: gs, hs, G, H, GS_k
   uint8_t* d_bases = nullptr;  // affine, 64 B each
   uint8_t* d_table = nullptr;  // fixed-base window table, see fixedbase.h
+  // transcript conventions the reference inherits from un-vendored packages
+  int show_style = 0;    // 0: derived Show "A (P x) (P y)" / "P s"; 1: plain "A x y" / "s"
+  int sqrt_branch = 0;   // 0: sr returns a^((p+1)/4); 1: the other root
+  // optional kernel timing with HIP events on the launching stream (bp_ctx_profile)
+  int profile = 0;
+  double prof_ms[2] = {0, 0};        // [0] k_fixed_multiexp, [1] k_light
+  uint64_t prof_calls[2] = {0, 0};
+  double prof_madds[2] = {0, 0};     // mixed additions those launches performed (nominal)
+  hipEvent_t msm_ev[2] = {nullptr, nullptr};
+  bool prof_pending_light = false;
 };
 
 #define BP_TRY(expr)                                                                          \

@@ -340,8 +340,27 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
   hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
   hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
+  if (ctx->profile) {  // the previous call's pair has completed on this in-order stream or is read after a sync
+    if (!ctx->msm_ev[0]) {
+      BP_TRY(hipEventCreate(&ctx->msm_ev[0]));
+      BP_TRY(hipEventCreate(&ctx->msm_ev[1]));
+    } else if (ctx->prof_pending_light) {
+      float ms = 0;
+      if (hipEventSynchronize(ctx->msm_ev[1]) == hipSuccess &&
+          hipEventElapsedTime(&ms, ctx->msm_ev[0], ctx->msm_ev[1]) == hipSuccess) {
+        ctx->prof_ms[1] += ms;
+        ctx->prof_calls[1] += 1;
+      }
+    }
+    BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
+  }
   hipLaunchKernelGGL(k_light, dim3((nbt32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs,
                      sorted, order, nbt32, buckets);
+  if (ctx->profile) {
+    BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
+    ctx->prof_pending_light = true;
+    ctx->prof_madds[1] += (double)wn;
+  }
   hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
   uint32_t hgrid = (uint32_t)(max_slices < 4096 ? max_slices : 4096);
   hipLaunchKernelGGL(k_heavy_slices, dim3(hgrid), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,

@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256) k_field_op(int field, int op, const uint8
       case 2: r = fq_mul(x, y); break;
       case 3: r = fq_sqr(x); break;
       case 4: r = fq_inv(x); break;
+      case 6: r = fq_sqrt_candidate(x); break;
       default: r = fq_neg(x); break;
     }
     r = fq_canon(r);
@@ -209,7 +210,7 @@ int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok)
 int bp_field_op(bp_ctx* ctx, int field, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
   if (!ctx) return BP_ERR_ARG;
   BP_REQUIRE(n == 0 || (a && b && out), "null pointer");
-  BP_REQUIRE(field >= 0 && field <= 2 && op >= 0 && op <= 5, "bad field/op selector");
+  BP_REQUIRE(field >= 0 && field <= 2 && op >= 0 && op <= 6 && (op != 6 || field == 0), "bad field/op selector");
   BP_CHECK_N(n);
   if (n == 0) return BP_OK;
   BP_TRY(hipSetDevice(ctx->device));

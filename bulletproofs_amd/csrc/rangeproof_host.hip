@@ -1,0 +1,431 @@
+// Host side of the drop-in: the control flow and Fiat-Shamir transcript of
+//   Bulletproofs.MultiRangeProof.verifyProof  (/root/reference/Bulletproofs/MultiRangeProof/Verifier.hs:19-39)
+//   Bulletproofs.RangeProof.verifyProof       (RangeProof/Verifier.hs:17-24)
+//   mkChallenges                              (InnerProductProof/Verifier.hs:40-53)
+//   gs / hs / h / generateH                   (Utils.hs:14-25,38-47)
+// written in C++ above the engine ABI (the reference is compiled Haskell and no
+// GHC exists in this image).  Hashing is multi-threaded over independent proofs
+// and ping-pongs with the GPU: the batch is cut into chunks, and while the GPU
+// runs one chunk's round the host hashes the other chunk's transcript.
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "engine.h"
+#include "transcript.h"
+#include "verify.h"
+
+using namespace bp;
+using namespace bp::host;
+
+namespace {
+
+// Minimal persistent worker pool: run(f, n) calls f(i) for i in [0, n) in blocks.
+class Pool {
+ public:
+  explicit Pool(int nthreads) : n_(nthreads < 1 ? 1 : nthreads) {
+    for (int t = 1; t < n_; t++) workers_.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      gen_++;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  int size() const { return n_; }
+  void run(const std::function<void(size_t, size_t)>& f, size_t n, size_t grain = 64) {
+    if (n == 0) return;
+    fn_ = &f;
+    total_ = n;
+    grain_ = grain;
+    next_.store(0);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      pending_ = n_ - 1;
+      gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      size_t a = next_.fetch_add(grain_);
+      if (a >= total_) break;
+      size_t b = a + grain_ < total_ ? a + grain_ : total_;
+      (*fn_)(a, b);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  int n_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  uint64_t gen_ = 0;
+  int pending_ = 0;
+  bool stop_ = false;
+  const std::function<void(size_t, size_t)>* fn_ = nullptr;
+  size_t total_ = 0, grain_ = 64;
+  std::atomic<size_t> next_{0};
+};
+
+int default_threads() {
+  const char* e = getenv("BP_HOST_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  unsigned hc = std::thread::hardware_concurrency();
+  if (hc == 0) hc = 1;
+  return (int)(hc > 16 ? 16 : hc);
+}
+
+struct Chunk {
+  bp_vbatch* vb = nullptr;
+  uint32_t B = 0;       // proofs in this chunk
+  size_t first = 0;     // index of its first proof in the job
+  // pinned host memory
+  uint8_t *sc = nullptr, *pts = nullptr, *chal = nullptr, *xk = nullptr, *acc = nullptr, *verdict = nullptr;
+};
+
+}  // namespace
+
+struct bp_vjob {
+  bp_ctx* ctx;
+  uint32_t n_bits, m, batch, k, npts;
+  ShowStyle style;
+  std::vector<Chunk> chunks;
+  Pool* pool;
+  void* pinned = nullptr;
+  bool loaded = false;
+};
+
+extern "C" {
+
+int bp_ctx_set_show_style(bp_ctx* ctx, int style) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(style == 0 || style == 1, "style must be 0 (derived Show) or 1 (plain)");
+  ctx->show_style = style;
+  return BP_OK;
+}
+
+int bp_ctx_set_sqrt_branch(bp_ctx* ctx, int branch) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(branch == 0 || branch == 1, "branch must be 0 or 1");
+  ctx->sqrt_branch = branch;
+  return BP_OK;
+}
+
+void bp_vjob_destroy(bp_vjob* job) {
+  if (!job) return;
+  (void)hipSetDevice(job->ctx->device);
+  for (auto& c : job->chunks)
+    if (c.vb) bp_vbatch_destroy(c.vb);
+  if (job->pinned) (void)hipHostFree(job->pinned);
+  delete job->pool;
+  delete job;
+}
+
+int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uint32_t n_chunks, int host_threads,
+                   bp_vjob** out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(out, "null pointer");
+  *out = nullptr;
+  BP_REQUIRE(batch >= 1, "batch must be >= 1");
+  if (n_chunks == 0) n_chunks = batch >= 4096 ? 2 : 1;
+  BP_REQUIRE(n_chunks <= 64 && n_chunks <= batch, "n_chunks out of range");
+  BP_TRY(hipSetDevice(ctx->device));
+  bp_vjob* job = new bp_vjob();
+  job->ctx = ctx;
+  job->n_bits = n_bits;
+  job->m = m;
+  job->batch = batch;
+  job->style = (ShowStyle)ctx->show_style;
+  job->pool = new Pool(host_threads > 0 ? host_threads : default_threads());
+  job->chunks.resize(n_chunks);
+  size_t per = (batch + n_chunks - 1) / n_chunks;
+  size_t first = 0, pinned_bytes = 0;
+  for (uint32_t c = 0; c < n_chunks; c++) {
+    Chunk& ch = job->chunks[c];
+    ch.first = first;
+    ch.B = (uint32_t)(first + per <= batch ? per : batch - first);
+    first += ch.B;
+    int rc = bp_vbatch_create(ctx, n_bits, m, ch.B, &ch.vb);
+    if (rc != BP_OK) {
+      bp_vjob_destroy(job);
+      return rc;
+    }
+    job->k = bp_vbatch_rounds(ch.vb);
+    job->npts = bp_vbatch_point_rows(ch.vb);
+    pinned_bytes += (size_t)ch.B * (5 * 32 + (size_t)job->npts * 64 + 4 * 32 + 32 + 64 + 1) + 6 * 256;
+  }
+  if (hipHostMalloc(&job->pinned, pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    job->pinned = nullptr;
+    bp_vjob_destroy(job);
+    ctx->err = "pinned host allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  Carver cv(job->pinned);
+  for (auto& ch : job->chunks) {
+    size_t B = ch.B;
+    ch.sc = cv.take<uint8_t>(5 * B * 32);
+    ch.pts = cv.take<uint8_t>((size_t)job->npts * B * 64);
+    ch.chal = cv.take<uint8_t>(4 * B * 32);
+    ch.xk = cv.take<uint8_t>(B * 32);
+    ch.acc = cv.take<uint8_t>(B * 64);
+    ch.verdict = cv.take<uint8_t>(B);
+  }
+  *out = job;
+  return BP_OK;
+}
+
+// scalars: 5 rows x batch x 32 B, points: rows x batch x 64 B (layout of bp_vbatch_load over the WHOLE batch).
+// Copies the proofs into pinned chunk-local arrays and uploads them to HBM.
+int bp_vjob_load(bp_vjob* job, const uint8_t* scalars, const uint8_t* points) {
+  if (!job) return BP_ERR_ARG;
+  bp_ctx* ctx = job->ctx;
+  BP_REQUIRE(scalars && points, "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  size_t Bt = job->batch;
+  for (auto& ch : job->chunks) {
+    size_t B = ch.B;
+    for (uint32_t r = 0; r < 5; r++) memcpy(ch.sc + r * B * 32, scalars + (r * Bt + ch.first) * 32, B * 32);
+    for (uint32_t r = 0; r < job->npts; r++) memcpy(ch.pts + r * B * 64, points + (r * Bt + ch.first) * 64, B * 64);
+    int rc = vbatch_load_async(ch.vb, ch.sc, ch.pts);
+    if (rc != BP_OK) return rc;
+  }
+  for (auto& ch : job->chunks) {
+    int rc = vbatch_wait(ch.vb);
+    if (rc != BP_OK) return rc;
+  }
+  job->loaded = true;
+  return BP_OK;
+}
+
+// The timed path: transcript hashing on the host, everything else on the GPU.
+int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
+  if (!job) return BP_ERR_ARG;
+  bp_ctx* ctx = job->ctx;
+  BP_REQUIRE(verdicts, "null pointer");
+  if (!job->loaded) {
+    ctx->err = "bp_vjob_run before bp_vjob_load";
+    return BP_ERR_STATE;
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  const ShowStyle st = job->style;
+  const uint32_t k = job->k;
+  int rc;
+  // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
+  for (auto& ch : job->chunks) {
+    const size_t B = ch.B;
+    job->pool->run(
+        [&](size_t a, size_t b) {
+          uint8_t buf[MSG_SCRATCH];
+          for (size_t p = a; p < b; p++) {
+            const uint8_t* A = ch.pts + ((size_t)VP_A * B + p) * 64;
+            const uint8_t* S = ch.pts + ((size_t)VP_S * B + p) * 64;
+            const uint8_t* T1 = ch.pts + ((size_t)VP_T1 * B + p) * 64;
+            const uint8_t* T2 = ch.pts + ((size_t)VP_T2 * B + p) * 64;
+            uint8_t* y = ch.chal + (0 * B + p) * 32;
+            uint8_t* z = ch.chal + (1 * B + p) * 32;
+            uint8_t* x = ch.chal + (2 * B + p) * 32;
+            uint8_t* u = ch.chal + (3 * B + p) * 32;
+            // shamirY: show _r <> A <> S   (Utils.hs:145-148)
+            Msg my(buf, st);
+            my.r();
+            my.point(A);
+            my.point(S);
+            size_t as_len = my.len;  // the text of show _r <> A <> S is shared by all three
+            uint8_t keep[MSG_SCRATCH];
+            memcpy(keep, buf, as_len);
+            my.finish_fr(y);
+            // shamirZ: ... <> show y   (Utils.hs:150-153)
+            Msg mz(buf, st);
+            mz.raw(keep, as_len);
+            mz.fr(y);
+            mz.finish_fr(z);
+            // shamirX: show _r <> A <> S <> T1 <> T2 <> show y <> show z   (Utils.hs:155-165)
+            Msg mx(buf, st);
+            mx.raw(keep, as_len);
+            mx.point(T1);
+            mx.point(T2);
+            mx.fr(y);
+            mx.fr(z);
+            mx.finish_fr(x);
+            // shamirU: show _r <> show tBlinding <> show mu <> show t   (Utils.hs:172-174)
+            Msg mu(buf, st);
+            mu.r();
+            mu.fr(ch.sc + ((size_t)VS_TAU * B + p) * 32);
+            mu.fr(ch.sc + ((size_t)VS_MU * B + p) * 32);
+            mu.fr(ch.sc + ((size_t)VS_T * B + p) * 32);
+            mu.finish_fr(u);
+          }
+        },
+        B);
+    if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc)) != BP_OK) return rc;
+  }
+  // mkChallenges (InnerProductProof/Verifier.hs:44-53)
+  for (uint32_t r = 0; r < k; r++) {
+    for (auto& ch : job->chunks) {
+      const size_t B = ch.B;
+      if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
+      job->pool->run(
+          [&](size_t a, size_t b) {
+            uint8_t buf[MSG_SCRATCH];
+            for (size_t p = a; p < b; p++) {
+              // shamirX' acc L R = oracle (show _r <> L <> R <> acc)   (Utils.hs:167-170)
+              Msg mm(buf, st);
+              mm.r();
+              mm.point(ch.pts + ((size_t)(VP_L0 + r) * B + p) * 64);
+              mm.point(ch.pts + ((size_t)(VP_L0 + k + r) * B + p) * 64);
+              mm.point(ch.acc + p * 64);
+              mm.finish_fr(ch.xk + p * 32);
+            }
+          },
+          B);
+      if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc)) != BP_OK) return rc;
+    }
+  }
+  for (auto& ch : job->chunks) {
+    if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
+    if ((rc = vbatch_finish_async(ch.vb, ch.verdict)) != BP_OK) return rc;
+  }
+  for (auto& ch : job->chunks) {
+    if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
+    memcpy(verdicts + ch.first, ch.verdict, ch.B);
+  }
+  return BP_OK;
+}
+
+int bp_rangeproof_verify_batch(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, const uint8_t* scalars,
+                               const uint8_t* points, uint8_t* verdicts) {
+  bp_vjob* job = nullptr;
+  int rc = bp_vjob_create(ctx, n_bits, m, batch, 0, 0, &job);
+  if (rc != BP_OK) return rc;
+  rc = bp_vjob_load(job, scalars, points);
+  if (rc == BP_OK) rc = bp_vjob_run(job, verdicts);
+  bp_vjob_destroy(job);
+  return rc;
+}
+
+// n = logBase2 upperBound = floor (logBase 2.0 (fromIntegral upperBound))   (Utils.hs:93-94,
+// MultiRangeProof/Verifier.hs:34): Double arithmetic, as in the reference.  upper_bound is a
+// little-endian integer of `len` bytes.
+int bp_log_base2(const uint8_t* upper_bound, size_t len) {
+  double v = 0.0;
+  for (size_t i = len; i-- > 0;) v = v * 256.0 + (double)upper_bound[i];  // exact prefix, then rounds like fromIntegral
+  if (!(v > 0.0)) return -1;
+  return (int)__builtin_floor(__builtin_log(v) / __builtin_log(2.0));
+}
+
+// Transcript self-test hook: which = 0 shamirY(A,S) 1 shamirZ(A,S,y) 2 shamirX(A,S,T1,T2,y,z)
+// 3 shamirX'(acc,L,R) 4 shamirU(tau,mu,t) 5 oracle over raw bytes into Fr 6 oracle into Fq.
+// pts: up to 4 points (64 B each), scs: up to 3 scalars (32 B each), raw/raw_len for 5, 6.
+int bp_transcript(int style, int which, const uint8_t* pts, const uint8_t* scs, const uint8_t* raw, size_t raw_len,
+                  uint8_t* out) {
+  if (!out || style < 0 || style > 1) return BP_ERR_ARG;
+  ShowStyle st = (ShowStyle)style;
+  std::vector<uint8_t> big(raw_len + MSG_SCRATCH);
+  Msg m(big.data(), st);
+  switch (which) {
+    case 0: m.r(); m.point(pts); m.point(pts + 64); break;
+    case 1: m.r(); m.point(pts); m.point(pts + 64); m.fr(scs); break;
+    case 2: m.r(); for (int i = 0; i < 4; i++) m.point(pts + 64 * i); m.fr(scs); m.fr(scs + 32); break;
+    case 3: m.r(); m.point(pts + 64); m.point(pts + 128); m.point(pts); break;
+    case 4: m.r(); m.fr(scs); m.fr(scs + 32); m.fr(scs + 64); break;
+    case 5: m.raw(raw, raw_len); break;
+    case 6: m.raw(raw, raw_len); oracle(m.buf, m.len, MOD_P, out); return BP_OK;
+    default: return BP_ERR_ARG;
+  }
+  m.finish_fr(out);
+  return BP_OK;
+}
+
+// The reference's generator CAFs (Utils.hs:14-25,38-47): h = generateH "", gs_i / hs_i =
+// gen * oracle(show i <> show gen / show h), i from 1.  Writes n_gens points each to gs_out,
+// hs_out and one to h_out (any may be null), and installs them with bp_ctx_set_generators.
+int bp_generators_derive(bp_ctx* ctx, uint32_t n_gens, uint8_t* gs_out, uint8_t* hs_out, uint8_t* h_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n_gens >= 1 && n_gens <= 8192 && (n_gens & (n_gens - 1)) == 0,
+             "n_gens must be a power of two in 1..8192");
+  ShowStyle st = (ShowStyle)ctx->show_style;
+  affine G = affine_gen();
+  uint8_t gen[64];
+  memcpy(gen, &G, 64);
+  // generateH (Utils.hs:38-47): x = oracle(show gen <> extra) in Fq, y = sr(x^3 + 7), retry with '1':extra
+  uint8_t hpt[64];
+  std::string extra;
+  int rc;
+  for (int attempt = 0;; attempt++) {
+    if (attempt > 256) {
+      ctx->err = "generateH did not terminate";
+      return BP_ERR_STATE;
+    }
+    uint8_t buf[MSG_SCRATCH + 300];
+    Msg m(buf, st);
+    m.point(gen);
+    m.raw(extra.data(), extra.size());
+    uint8_t x[32], y[32], x2[32], x3[32], rhs[32], seven[32] = {7}, chk[32];
+    oracle(m.buf, m.len, MOD_P, x);
+    if ((rc = bp_field_op(ctx, 0, 3, x, x, 1, x2)) != BP_OK) return rc;
+    if ((rc = bp_field_op(ctx, 0, 2, x2, x, 1, x3)) != BP_OK) return rc;
+    if ((rc = bp_field_op(ctx, 0, 0, x3, seven, 1, rhs)) != BP_OK) return rc;
+    if ((rc = bp_field_op(ctx, 0, 6, rhs, rhs, 1, y)) != BP_OK) return rc;  // sr: (p+1)/4 power
+    if ((rc = bp_field_op(ctx, 0, 3, y, y, 1, chk)) != BP_OK) return rc;
+    if (memcmp(chk, rhs, 32) == 0) {
+      if (ctx->sqrt_branch == 1) {  // U2 alternative: the other root
+        uint8_t ny[32];
+        if ((rc = bp_field_op(ctx, 0, 5, y, y, 1, ny)) != BP_OK) return rc;
+        memcpy(y, ny, 32);
+      }
+      memcpy(hpt, x, 32);
+      memcpy(hpt + 32, y, 32);
+      break;
+    }
+    extra = "1" + extra;
+  }
+  // gs, hs
+  std::vector<uint8_t> sc((size_t)2 * n_gens * 32), base((size_t)2 * n_gens * 64), out((size_t)2 * n_gens * 64);
+  for (uint32_t i = 0; i < n_gens; i++) {
+    uint8_t buf[MSG_SCRATCH];
+    char num[16];
+    int nl = snprintf(num, sizeof num, "%u", i + 1);
+    Msg mg(buf, st);
+    mg.raw(num, (size_t)nl);
+    mg.point(gen);
+    mg.finish_fr(&sc[(size_t)i * 32]);
+    Msg mh(buf, st);
+    mh.raw(num, (size_t)nl);
+    mh.point(hpt);
+    mh.finish_fr(&sc[(size_t)(n_gens + i) * 32]);
+    memcpy(&base[(size_t)i * 64], gen, 64);
+    memcpy(&base[(size_t)(n_gens + i) * 64], gen, 64);
+  }
+  if ((rc = bp_point_mul(ctx, sc.data(), base.data(), (size_t)2 * n_gens, out.data())) != BP_OK) return rc;
+  if (gs_out) memcpy(gs_out, out.data(), (size_t)n_gens * 64);
+  if (hs_out) memcpy(hs_out, out.data() + (size_t)n_gens * 64, (size_t)n_gens * 64);
+  if (h_out) memcpy(h_out, hpt, 64);
+  return bp_ctx_set_generators(ctx, out.data(), out.data() + (size_t)n_gens * 64, hpt, n_gens);
+}
+
+}  // extern "C"

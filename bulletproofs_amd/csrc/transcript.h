@@ -1,0 +1,290 @@
+// Host-side Fiat-Shamir transcript of the reference, kept on the CPU as
+// BASELINE.json's north_star asks:
+//   oracle = fromInteger . integerDigest . sha256   (/root/reference/Bulletproofs/Utils.hs:29-30)
+//   pointToBS = show                                 (Utils.hs:32-33)
+//   shamirY / shamirZ / shamirX / shamirX' / shamirU (Utils.hs:145-174)
+// The hashed bytes are the Haskell `show` text of points and scalars (decimal),
+// so this file is: 256-bit -> decimal, the `show` formats, SHA-256 (SHA-NI when
+// the CPU has it), and the reduction of the digest into Fr / Fq.
+//
+// PARITY NOTE: the `show` format is defined by the un-vendored
+// packages elliptic-curve-0.3.0 / galois-field-1.0.0.  Both candidates are
+// implemented; SHOW_DERIVED ("A (P x) (P y)", "P s") is the default.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#if defined(__x86_64__)
+#include <cpuid.h>
+#include <immintrin.h>
+#endif
+
+namespace bp {
+namespace host {
+
+enum ShowStyle { SHOW_DERIVED = 0, SHOW_PLAIN = 1 };
+
+// ---- SHA-256 ---------------------------------------------------------------------------
+static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98,
+    0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786,
+    0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8,
+    0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819,
+    0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a,
+    0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7,
+    0xc67178f2};
+
+static inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+static inline void sha256_blocks_portable(uint32_t st[8], const uint8_t* p, size_t nblk) {
+  for (; nblk; nblk--, p += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+      w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+      uint32_t ch = (e & f) ^ (~e & g);
+      uint32_t t1 = h + S1 + ch + SHA_K[i] + w[i];
+      uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+      uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+      uint32_t t2 = S0 + mj;
+      h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+  }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_shani(uint32_t st[8], const uint8_t* p,
+                                                                                    size_t nblk) {
+  const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+  __m128i tmp = _mm_loadu_si128((const __m128i*)&st[0]);     // DCBA
+  __m128i s1 = _mm_loadu_si128((const __m128i*)&st[4]);      // HGFE
+  tmp = _mm_shuffle_epi32(tmp, 0xB1);                        // CDAB
+  s1 = _mm_shuffle_epi32(s1, 0x1B);                          // EFGH
+  __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                  // ABEF
+  s1 = _mm_blend_epi16(s1, tmp, 0xF0);                       // CDGH
+  for (; nblk; nblk--, p += 64) {
+    __m128i abef = s0, cdgh = s1;
+    __m128i m[4];
+    for (int i = 0; i < 4; i++) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16 * i)), MASK);
+    for (int r = 0; r < 16; r++) {
+      __m128i msg = _mm_add_epi32(m[r & 3], _mm_loadu_si128((const __m128i*)&SHA_K[4 * r]));
+      s1 = _mm_sha256rnds2_epu32(s1, s0, msg);
+      msg = _mm_shuffle_epi32(msg, 0x0E);
+      s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
+      if (r < 12) {
+        // schedule W[4(r+4) .. 4(r+4)+3] into m[r & 3]
+        __m128i w0 = m[r & 3], w1 = m[(r + 1) & 3], w2 = m[(r + 2) & 3], w3 = m[(r + 3) & 3];
+        __m128i t = _mm_sha256msg1_epu32(w0, w1);
+        t = _mm_add_epi32(t, _mm_alignr_epi8(w3, w2, 4));
+        m[r & 3] = _mm_sha256msg2_epu32(t, w3);
+      }
+    }
+    s0 = _mm_add_epi32(s0, abef);
+    s1 = _mm_add_epi32(s1, cdgh);
+  }
+  tmp = _mm_shuffle_epi32(s0, 0x1B);                         // FEBA
+  s1 = _mm_shuffle_epi32(s1, 0xB1);                          // DCHG
+  s0 = _mm_blend_epi16(tmp, s1, 0xF0);                       // DCBA
+  s1 = _mm_alignr_epi8(s1, tmp, 8);                          // HGFE
+  _mm_storeu_si128((__m128i*)&st[0], s0);
+  _mm_storeu_si128((__m128i*)&st[4], s1);
+}
+static inline bool cpu_has_shani() {
+  static int cached = -1;
+  if (cached < 0) {
+    unsigned a, b, c, d;
+    cached = (__get_cpuid_count(7, 0, &a, &b, &c, &d) && (b & (1u << 29))) ? 1 : 0;
+  }
+  return cached == 1;
+}
+#endif
+
+static inline void sha256_blocks(uint32_t st[8], const uint8_t* p, size_t nblk) {
+#if defined(__x86_64__)
+  if (cpu_has_shani()) {
+    sha256_blocks_shani(st, p, nblk);
+    return;
+  }
+#endif
+  sha256_blocks_portable(st, p, nblk);
+}
+
+// one-shot digest of a message with >= 72 bytes of writable slack after it (padding is
+// written in place; callers build messages in scratch buffers)
+static inline void sha256_inplace(uint8_t* msg, size_t len, uint8_t out[32]) {
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  size_t total = len;
+  msg[total++] = 0x80;
+  while ((total & 63) != 56) msg[total++] = 0;
+  uint64_t bits = (uint64_t)len * 8;
+  for (int i = 7; i >= 0; i--) msg[total++] = (uint8_t)(bits >> (8 * i));
+  sha256_blocks(st, msg, total / 64);
+  for (int i = 0; i < 8; i++) {
+    out[4 * i] = (uint8_t)(st[i] >> 24);
+    out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(st[i] >> 8);
+    out[4 * i + 3] = (uint8_t)st[i];
+  }
+}
+
+// ---- 256-bit little-endian integer -> decimal text ------------------------------------------
+static inline uint64_t div_u128_u64(uint64_t hi, uint64_t lo, uint64_t d, uint64_t* rem) {
+#if defined(__x86_64__)
+  uint64_t q, r;
+  __asm__("divq %4" : "=a"(q), "=d"(r) : "a"(lo), "d"(hi), "r"(d) : "cc");
+  *rem = r;
+  return q;
+#else
+  unsigned __int128 n = ((unsigned __int128)hi << 64) | lo;
+  *rem = (uint64_t)(n % d);
+  return (uint64_t)(n / d);
+#endif
+}
+
+// writes the decimal digits of the 32-byte LE integer, returns the length (no terminator)
+static inline size_t u256_to_dec(const uint8_t le[32], char* out) {
+  uint64_t v[4];
+  memcpy(v, le, 32);
+  int top = 3;
+  while (top >= 0 && v[top] == 0) top--;
+  if (top < 0) {
+    out[0] = '0';
+    return 1;
+  }
+  const uint64_t TEN19 = 10000000000000000000ULL;
+  uint64_t chunk[5];
+  int nchunk = 0;
+  while (top >= 0) {
+    uint64_t rem = 0;
+    for (int i = top; i >= 0; i--) v[i] = div_u128_u64(rem, v[i], TEN19, &rem);
+    chunk[nchunk++] = rem;
+    while (top >= 0 && v[top] == 0) top--;
+  }
+  char* o = out;
+  // most significant chunk without leading zeros
+  {
+    char tmp[20];
+    int n = 0;
+    uint64_t c = chunk[nchunk - 1];
+    do {
+      tmp[n++] = (char)('0' + c % 10);
+      c /= 10;
+    } while (c);
+    while (n) *o++ = tmp[--n];
+  }
+  for (int k = nchunk - 2; k >= 0; k--) {
+    uint64_t c = chunk[k];
+    for (int i = 18; i >= 0; i--) {
+      o[i] = (char)('0' + c % 10);
+      c /= 10;
+    }
+    o += 19;
+  }
+  return (size_t)(o - out);
+}
+
+// `show (s :: Fr)`  (Utils.hs:153,165,174)
+static inline size_t show_fr(ShowStyle st, const uint8_t s[32], char* out) {
+  char* o = out;
+  if (st == SHOW_DERIVED) {
+    *o++ = 'P';
+    *o++ = ' ';
+  }
+  o += u256_to_dec(s, o);
+  return (size_t)(o - out);
+}
+
+// `pointToBS = show`  (Utils.hs:32-33); 64 zero bytes encode `O`
+static inline size_t show_point(ShowStyle st, const uint8_t pt[64], char* out) {
+  bool inf = true;
+  for (int i = 0; i < 64; i++)
+    if (pt[i]) {
+      inf = false;
+      break;
+    }
+  char* o = out;
+  if (inf) {
+    *o++ = 'O';
+    return 1;
+  }
+  if (st == SHOW_DERIVED) {
+    memcpy(o, "A (P ", 5);
+    o += 5;
+    o += u256_to_dec(pt, o);
+    memcpy(o, ") (P ", 5);
+    o += 5;
+    o += u256_to_dec(pt + 32, o);
+    *o++ = ')';
+  } else {
+    *o++ = 'A';
+    *o++ = ' ';
+    o += u256_to_dec(pt, o);
+    *o++ = ' ';
+    o += u256_to_dec(pt + 32, o);
+  }
+  return (size_t)(o - out);
+}
+
+static const char SHOW_R[] = "115792089237316195423570985008687907852837564279074904382605163141518161494337";
+static const size_t SHOW_R_LEN = sizeof(SHOW_R) - 1;
+// little-endian 64-bit limbs
+static const uint64_t MOD_R[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL,
+                                  0xFFFFFFFFFFFFFFFFULL};
+static const uint64_t MOD_P[4] = {0xFFFFFFFEFFFFFC2FULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL,
+                                  0xFFFFFFFFFFFFFFFFULL};
+
+// digest (big-endian integer) mod m -> 32 bytes little-endian; 2^256 < 2m for both moduli
+static inline void digest_mod(const uint8_t digest[32], const uint64_t m[4], uint8_t out_le[32]) {
+  uint64_t v[4];
+  for (int i = 0; i < 4; i++) {
+    uint64_t w = 0;
+    for (int j = 0; j < 8; j++) w = (w << 8) | digest[8 * (3 - i) + j];
+    v[i] = w;
+  }
+  uint64_t d[4];
+  unsigned __int128 bw = 0;
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 t = (unsigned __int128)v[i] - m[i] - (uint64_t)bw;
+    d[i] = (uint64_t)t;
+    bw = (t >> 64) & 1;
+  }
+  memcpy(out_le, bw ? v : d, 32);
+}
+
+// `oracle` (Utils.hs:29-30); msg needs 72 bytes of slack (sha256_inplace)
+static inline void oracle(uint8_t* msg, size_t len, const uint64_t m[4], uint8_t out_le[32]) {
+  uint8_t dg[32];
+  sha256_inplace(msg, len, dg);
+  digest_mod(dg, m, out_le);
+}
+
+// Incremental message builder over a caller-provided scratch buffer
+struct Msg {
+  uint8_t* buf;
+  size_t len;
+  ShowStyle st;
+  Msg(uint8_t* b, ShowStyle s) : buf(b), len(0), st(s) {}
+  void r() {
+    memcpy(buf + len, SHOW_R, SHOW_R_LEN);
+    len += SHOW_R_LEN;
+  }
+  void point(const uint8_t* p) { len += show_point(st, p, (char*)buf + len); }
+  void fr(const uint8_t* s) { len += show_fr(st, s, (char*)buf + len); }
+  void raw(const void* p, size_t n) {
+    memcpy(buf + len, p, n);
+    len += n;
+  }
+  void finish_fr(uint8_t out_le[32]) { oracle(buf, len, MOD_R, out_le); }
+};
+constexpr size_t MSG_SCRATCH = 1280;  // longest transcript: shamirX, 8 numbers + show_r + slack
+
+}  // namespace host
+}  // namespace bp

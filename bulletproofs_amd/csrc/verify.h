@@ -1,6 +1,8 @@
 // Shared definitions of the batch verifier (verify.hip, host/rangeproof_host.cpp).
 #pragma once
 #include <stdint.h>
+#include "engine.h"
+#include "fixedbase.h"
 
 namespace bp {
 
@@ -25,4 +27,35 @@ inline uint32_t vbatch_lpp(uint32_t B) {
   return lpp;
 }
 
+}  // namespace bp
+
+// One batch of proofs of a single shape, in lock-step (include/bpgpu.h bp_vbatch_*).
+// Owns its stream and pinned staging so that two batches can ping-pong: the host
+// hashes one while the GPU works on the other.
+struct bp_vbatch {
+  bp_ctx* ctx;
+  bp::VDims d;
+  bp::DevBuf buf;
+  hipStream_t stream;
+  // device
+  uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
+  bp::u256 *cst, *ypowinv, *zpow, *xk_m, *xkinv_m;
+  uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
+  bp::xyzz *acc1, *acc2;
+  uint32_t nt1, nt3a, nt3b, npts;
+  int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
+  // profiling: event pairs around the three k_fixed_multiexp launches
+  hipEvent_t ev[3][2];
+  bool ev_pending[3];
+  double ev_madds[3];
+};
+
+namespace bp {
+// Asynchronous forms (enqueue on vb->stream, no synchronisation); the host buffers
+// must stay valid until the stream has been synchronised (use pinned memory for overlap).
+int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points);
+int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment);
+int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment);
+int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
+int vbatch_wait(bp_vbatch* vb);
 }  // namespace bp

@@ -282,21 +282,119 @@ __global__ void __launch_bounds__(256) k_verdict(VDims d, const xyzz* __restrict
 
 using namespace bp;
 
-// ------------------------------------------------------------------------------------------------
-struct bp_vbatch {
-  bp_ctx* ctx;
-  VDims d;
-  DevBuf buf;
-  // device
-  uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
-  u256 *cst, *ypowinv, *zpow, *xk_m, *xkinv_m;
-  uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
-  xyzz *acc1, *acc2;
-  uint32_t nt1, nt3a, nt3b, npts;
-  int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
-};
+#define VB_GRID(n) dim3((unsigned)((((size_t)(n)) + 255) / 256)), dim3(256), 0, vb->stream
 
-#define VB_GRID(n) dim3((unsigned)((((size_t)(n)) + 255) / 256)), dim3(256), 0, ctx->stream
+namespace bp {
+
+// HIP-event timing of k_fixed_multiexp on the launching stream (bp_ctx_profile)
+static inline void prof_begin(bp_vbatch* vb, int slot, uint32_t nterms) {
+  if (!vb->ctx->profile) return;
+  (void)hipEventRecord(vb->ev[slot][0], vb->stream);
+  vb->ev_madds[slot] = (double)vb->d.B * nterms * 32.0;  // 8-bit windows over 256 bits
+}
+static inline void prof_end(bp_vbatch* vb, int slot) {
+  if (!vb->ctx->profile) return;
+  (void)hipEventRecord(vb->ev[slot][1], vb->stream);
+  vb->ev_pending[slot] = true;
+}
+
+int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
+  bp_ctx* ctx = vb->ctx;
+  size_t B = vb->d.B;
+  BP_TRY(hipMemcpyAsync(vb->sc, scalars, 5 * B * 32, hipMemcpyHostToDevice, vb->stream));
+  BP_TRY(hipMemcpyAsync(vb->pts, points, (size_t)vb->npts * B * 64, hipMemcpyHostToDevice, vb->stream));
+  vb->stage = 1;
+  return BP_OK;
+}
+
+int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->stage < 1) {
+    ctx->err = "bp_vbatch_begin before bp_vbatch_load";
+    return BP_ERR_STATE;
+  }
+  VDims d = vb->d;
+  size_t B = d.B;
+  BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
+  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow);
+  hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
+  uint32_t lpp = vbatch_lpp(d.B);
+  prof_begin(vb, 0, vb->nt1);
+  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt1, lpp, vb->dig1, vb->tb1, ctx->d_table, vb->acc1);
+  prof_end(vb, 0);
+  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->acc_aff);
+  BP_TRY(hipGetLastError());
+  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
+  vb->stage = 2;
+  return BP_OK;
+}
+
+int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->stage != (int)(2 + round) || round >= vb->d.k) {
+    ctx->err = "bp_vbatch_round out of order";
+    return BP_ERR_STATE;
+  }
+  VDims d = vb->d;
+  size_t B = d.B;
+  BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, vb->stream));
+  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->acc_aff);
+  BP_TRY(hipGetLastError());
+  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
+  vb->stage++;
+  return BP_OK;
+}
+
+int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->stage != (int)(2 + vb->d.k)) {
+    ctx->err = "bp_vbatch_finish before all rounds";
+    return BP_ERR_STATE;
+  }
+  VDims d = vb->d;
+  size_t B = d.B;
+  hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xkinv_m, vb->cst);
+  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->xk_m,
+                     vb->dig3a, vb->dig3b, vb->vs);
+  uint32_t lpp = vbatch_lpp(d.B);
+  prof_begin(vb, 1, vb->nt3a);
+  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt3a, lpp, vb->dig3a, vb->tb3a, ctx->d_table,
+                     vb->acc1);
+  prof_end(vb, 1);
+  prof_begin(vb, 2, vb->nt3b);
+  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B), d.B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, ctx->d_table, vb->acc2);
+  prof_end(vb, 2);
+  uint32_t nv = d.m + 2;
+  uint32_t j = 0;
+  if (nv & 1u) {  // m = 1: three terms, one pass of three
+    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID(B), d, 0u, vb->pts, vb->vs, vb->acc2);
+    j = 3;
+  }
+  for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->acc2);
+  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict);
+  BP_TRY(hipGetLastError());
+  BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
+  vb->stage = 1;  // may be begun again with the same loaded proofs
+  return BP_OK;
+}
+
+int vbatch_wait(bp_vbatch* vb) {
+  bp_ctx* ctx = vb->ctx;
+  BP_TRY(hipStreamSynchronize(vb->stream));
+  for (int s = 0; s < 3; s++)
+    if (vb->ev_pending[s]) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, vb->ev[s][0], vb->ev[s][1]) == hipSuccess) {
+        ctx->prof_ms[0] += ms;
+        ctx->prof_calls[0] += 1;
+        ctx->prof_madds[0] += vb->ev_madds[s];
+      }
+      vb->ev_pending[s] = false;
+    }
+  return BP_OK;
+}
+
+}  // namespace bp
 
 extern "C" {
 
@@ -316,6 +414,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   BP_TRY(hipSetDevice(ctx->device));
   bp_vbatch* vb = new bp_vbatch();
   vb->ctx = ctx;
+  vb->stream = nullptr;
   VDims& d = vb->d;
   d.B = batch;
   d.n = n_bits;
@@ -353,7 +452,15 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     return c.off;
   };
   size_t need = carve(nullptr);
-  if (vb->buf.reserve(need) != 0) {
+  hipError_t e = hipStreamCreateWithFlags(&vb->stream, hipStreamNonBlocking);
+  for (int s2 = 0; s2 < 3; s2++) {
+    vb->ev_pending[s2] = false;
+    vb->ev[s2][0] = vb->ev[s2][1] = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][0]);
+    if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][1]);
+  }
+  if (e != hipSuccess || vb->buf.reserve(need) != 0) {
+    if (vb->stream) (void)hipStreamDestroy(vb->stream);
     delete vb;
     ctx->err = "verifier workspace allocation failed";
     return BP_ERR_NOMEM;
@@ -373,12 +480,13 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   tb3a[2 * nm] = fb_base_G(ng);
   tb3b[0] = fb_base_G(ng);
   tb3b[1] = fb_base_H(ng);
-  hipError_t e = hipMemcpyAsync(vb->tb1, tb1.data(), tb1.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(vb->tb3a, tb3a.data(), tb3a.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(vb->tb3b, tb3b.data(), tb3b.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  e = hipMemcpyAsync(vb->tb1, tb1.data(), tb1.size() * 4, hipMemcpyHostToDevice, vb->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(vb->tb3a, tb3a.data(), tb3a.size() * 4, hipMemcpyHostToDevice, vb->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(vb->tb3b, tb3b.data(), tb3b.size() * 4, hipMemcpyHostToDevice, vb->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(vb->stream);
   if (e != hipSuccess) {
     vb->buf.release();
+    (void)hipStreamDestroy(vb->stream);
     delete vb;
     ctx->err = std::string("bp_vbatch_create: ") + hipGetErrorString(e);
     return BP_ERR_DEVICE;
@@ -391,8 +499,12 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
 void bp_vbatch_destroy(bp_vbatch* vb) {
   if (!vb) return;
   (void)hipSetDevice(vb->ctx->device);
-  (void)hipStreamSynchronize(vb->ctx->stream);
+  (void)hipStreamSynchronize(vb->stream);
   vb->buf.release();
+  for (int s = 0; s < 3; s++)
+    for (int j = 0; j < 2; j++)
+      if (vb->ev[s][j]) (void)hipEventDestroy(vb->ev[s][j]);
+  (void)hipStreamDestroy(vb->stream);
   delete vb;
 }
 
@@ -404,88 +516,35 @@ int bp_vbatch_load(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points)
   bp_ctx* ctx = vb->ctx;
   BP_REQUIRE(scalars && points, "null pointer");
   BP_TRY(hipSetDevice(ctx->device));
-  size_t B = vb->d.B;
-  BP_TRY(hipMemcpyAsync(vb->sc, scalars, 5 * B * 32, hipMemcpyHostToDevice, ctx->stream));
-  BP_TRY(hipMemcpyAsync(vb->pts, points, (size_t)vb->npts * B * 64, hipMemcpyHostToDevice, ctx->stream));
-  vb->stage = 1;
-  return BP_OK;
+  int rc = vbatch_load_async(vb, scalars, points);
+  return rc != BP_OK ? rc : vbatch_wait(vb);
 }
 
 int bp_vbatch_begin(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment) {
   if (!vb) return BP_ERR_ARG;
   bp_ctx* ctx = vb->ctx;
   BP_REQUIRE(challenges && out_commitment, "null pointer");
-  if (vb->stage < 1) {
-    ctx->err = "bp_vbatch_begin before bp_vbatch_load";
-    return BP_ERR_STATE;
-  }
   BP_TRY(hipSetDevice(ctx->device));
-  VDims d = vb->d;
-  size_t B = d.B;
-  BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow);
-  hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
-  uint32_t lpp = vbatch_lpp(d.B);
-  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt1, lpp, vb->dig1, vb->tb1, ctx->d_table, vb->acc1);
-  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->acc_aff);
-  BP_TRY(hipGetLastError());
-  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, ctx->stream));
-  BP_TRY(hipStreamSynchronize(ctx->stream));
-  vb->stage = 2;
-  return BP_OK;
+  int rc = vbatch_begin_async(vb, challenges, out_commitment);
+  return rc != BP_OK ? rc : vbatch_wait(vb);
 }
 
 int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment) {
   if (!vb) return BP_ERR_ARG;
   bp_ctx* ctx = vb->ctx;
   BP_REQUIRE(x && out_commitment, "null pointer");
-  if (vb->stage != (int)(2 + round) || round >= vb->d.k) {
-    ctx->err = "bp_vbatch_round out of order";
-    return BP_ERR_STATE;
-  }
   BP_TRY(hipSetDevice(ctx->device));
-  VDims d = vb->d;
-  size_t B = d.B;
-  BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->acc_aff);
-  BP_TRY(hipGetLastError());
-  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, ctx->stream));
-  BP_TRY(hipStreamSynchronize(ctx->stream));
-  vb->stage++;
-  return BP_OK;
+  int rc = vbatch_round_async(vb, round, x, out_commitment);
+  return rc != BP_OK ? rc : vbatch_wait(vb);
 }
 
 int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts) {
   if (!vb) return BP_ERR_ARG;
   bp_ctx* ctx = vb->ctx;
   BP_REQUIRE(verdicts, "null pointer");
-  if (vb->stage != (int)(2 + vb->d.k)) {
-    ctx->err = "bp_vbatch_finish before all rounds";
-    return BP_ERR_STATE;
-  }
   BP_TRY(hipSetDevice(ctx->device));
-  VDims d = vb->d;
-  size_t B = d.B;
-  hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xkinv_m, vb->cst);
-  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->xk_m,
-                     vb->dig3a, vb->dig3b, vb->vs);
-  uint32_t lpp = vbatch_lpp(d.B);
-  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt3a, lpp, vb->dig3a, vb->tb3a, ctx->d_table,
-                     vb->acc1);
-  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B), d.B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, ctx->d_table, vb->acc2);
-  uint32_t nv = d.m + 2;
-  uint32_t j = 0;
-  if (nv & 1u) {  // m = 1: three terms, one pass of three
-    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID(B), d, 0u, vb->pts, vb->vs, vb->acc2);
-    j = 3;
-  }
-  for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->acc2);
-  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict);
-  BP_TRY(hipGetLastError());
-  BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, ctx->stream));
-  BP_TRY(hipStreamSynchronize(ctx->stream));
-  vb->stage = 1;  // may be begun again with the same loaded proofs
-  return BP_OK;
+  int rc = vbatch_finish_async(vb, verdicts);
+  return rc != BP_OK ? rc : vbatch_wait(vb);
 }
 
 }  // extern "C"

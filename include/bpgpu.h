@@ -54,6 +54,14 @@ int bp_ctx_sync(bp_ctx* ctx);
 /* The context's hipStream_t, as an opaque pointer. */
 void* bp_ctx_stream(bp_ctx* ctx);
 
+/* Kernel timing for the benchmark's roofline line: when enabled, the two dominant kernels are
+ * bracketed with HIP events on the stream they are launched on.  kernel 0 = k_fixed_multiexp
+ * (batch verifier), 1 = k_light (MSM bucket accumulation).  Returns the accumulated device
+ * time, launch count and the number of mixed point additions those launches performed.
+ * bp_ctx_profile(ctx, x) also resets the counters.  No counterpart in the reference. */
+int bp_ctx_profile(bp_ctx* ctx, int enable);
+int bp_ctx_profile_read(bp_ctx* ctx, int kernel, double* total_ms, uint64_t* launches, double* mixed_adds);
+
 /* ---- element-wise group operations (batches of n independent operations) ----
  *
  * bp_point_mul      out[i] = scalars[i] * points[i]
@@ -135,8 +143,52 @@ int bp_vbatch_begin(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commi
 int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment);
 int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts);
 
+/* ---- host-side protocol layer (transcript on the CPU, curve work on the GPU) ----
+ *
+ * These mirror the reference's own functions one level above the engine: they
+ * contain the Fiat-Shamir hashing (`oracle`, `shamir*`, Utils.hs:29-33,145-174)
+ * and the control flow, multi-threaded over independent proofs.
+ *
+ * bp_ctx_set_show_style   text format `show` gives points/scalars in transcripts
+ *                   (0 = derived Show "A (P x) (P y)" / "P s", the default; 1 = "A x y" / "s").
+ *                   The format is defined by packages outside the reference tree.
+ * bp_ctx_set_sqrt_branch  which root `sr` returns in generateH (0 = a^((p+1)/4), 1 = the other).
+ * bp_generators_derive    evaluates `h`, `take n gs`, `take n hs` (Utils.hs:14-25,38-47), returns
+ *                   them (outputs may be NULL) and installs them with bp_ctx_set_generators.
+ * bp_log_base2      `logBase2` (Utils.hs:93-94) on a little-endian integer, in Double arithmetic
+ *                   as the reference does; -1 for zero.
+ * bp_transcript     the reference's hash-to-scalar functions, for parity tests:
+ *                   which = 0 shamirY(A,S)  1 shamirZ(A,S,y)  2 shamirX(A,S,T1,T2,y,z)
+ *                   3 shamirX'(acc,L,R) [pts = acc,L,R]  4 shamirU(tBlinding,mu,t)
+ *                   5 oracle(raw) into Fr  6 oracle(raw) into Fq.  out: 32 bytes.
+ *
+ * bp_rangeproof_verify_batch   verdicts[i] = MultiRangeProof.verifyProof 2^n_bits vCommits_i proof_i
+ *                   (MultiRangeProof/Verifier.hs:19-39; m = 1 is RangeProof.verifyProof,
+ *                   RangeProof/Verifier.hs:17-24) for `batch` independent proofs = `map verifyProof`.
+ *                   scalars / points use the bp_vbatch_load layout over the whole batch;
+ *                   vCommits are already padded to m = 2^ceil(log2 m) with O.
+ * bp_vjob_*         the same split into create (workspaces, pinned staging, worker threads),
+ *                   load (proofs -> pinned host + HBM) and run (the transcript + GPU pipeline);
+ *                   n_chunks = 0 and host_threads = 0 pick defaults (env BP_HOST_THREADS).
+ */
+int bp_ctx_set_show_style(bp_ctx* ctx, int style);
+int bp_ctx_set_sqrt_branch(bp_ctx* ctx, int branch);
+int bp_generators_derive(bp_ctx* ctx, uint32_t n_gens, uint8_t* gs_out, uint8_t* hs_out, uint8_t* h_out);
+int bp_log_base2(const uint8_t* upper_bound, size_t len);
+int bp_transcript(int style, int which, const uint8_t* pts, const uint8_t* scs, const uint8_t* raw, size_t raw_len,
+                  uint8_t* out);
+int bp_rangeproof_verify_batch(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, const uint8_t* scalars,
+                               const uint8_t* points, uint8_t* verdicts);
+typedef struct bp_vjob bp_vjob;
+int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uint32_t n_chunks, int host_threads,
+                   bp_vjob** out);
+void bp_vjob_destroy(bp_vjob* job);
+int bp_vjob_load(bp_vjob* job, const uint8_t* scalars, const uint8_t* points);
+int bp_vjob_run(bp_vjob* job, uint8_t* verdicts);
+
 /* ---- field arithmetic self-test hooks (used by the parity tests) ----
- * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a)
+ * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a),
+ *     6 a^((p+1)/4), the square-root candidate `sr` uses (field 0 only; Utils.hs:47)
  * field: 0 = Fq (base field, pseudo-Mersenne path), 1 = Fr (Montgomery path),
  *        2 = Fq through the generic Montgomery path
  * a, b, out: n canonical 32-byte elements.  Replaces `+ - * recip negate` on

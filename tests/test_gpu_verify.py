@@ -126,3 +126,39 @@ def test_bench_proof_golden(eng_gens):
     assert got[3:] == [o.rp_verify_proof(2**64, vc, p) for p in batch_p[3:]]
     # commitment to v+1 must not verify (RangeProof.hs:183-194)
     assert run_batch(eng_gens, 64, 1, [pr], [[o.commit(b["v"] + 1, b["vBlinding"])]], check_trace=False) == [False]
+
+
+def test_derive_generators_matches_oracle(engine):
+    """Utils.hs:14-25: h, gs, hs as the engine's host layer evaluates them."""
+    g, hh, h1 = engine.derive_generators(8)
+    assert h1 == o.h() and g == o.gs(8) and hh == o.hs(8)
+    engine.set_generators(o.gs(128), o.hs(128), o.h())  # restore for the other tests
+
+
+def test_host_layer_verify_batch(eng_gens):
+    """bp_rangeproof_verify_batch = map verifyProof, transcript hashed by the C++ host layer;
+    chunked ping-pong pipeline must give the same verdicts as one chunk."""
+    rng = random.Random(77)
+    n, m = 8, 2
+    proofs, vcs = [], []
+    for _ in range(4):
+        vs = [(rng.randrange(0, 2**n), rng.randrange(1, R)) for _ in range(m)]
+        proofs.append(o.mrp_generate_proof(2**n, vs, *o.draw_blinders(rng, n * m)))
+        vcs.append([o.commit(v, b) for v, b in vs])
+    all_p, all_v = [], []
+    for i in range(37):
+        if i % 3 == 0:
+            p, v = mutate(rng, proofs[i % 4], vcs[i % 4])
+        else:
+            p, v = proofs[i % 4], vcs[i % 4]
+        all_p.append(p)
+        all_v.append(v)
+    exp = [o.mrp_verify_proof(2**n, v, p) for p, v in zip(all_p, all_v)]
+    sc, pts, _ = pack_batch(all_p, all_v, m)
+    assert eng_gens.verify_batch(n, m, len(all_p), sc, pts) == exp
+    for chunks, threads in [(1, 1), (3, 2), (5, 4)]:
+        job = eng_gens.vjob(n, m, len(all_p), chunks, threads)
+        job.load(sc, pts)
+        assert [b != 0 for b in job.run()] == exp
+        assert [b != 0 for b in job.run()] == exp  # re-runnable
+        job.close()
