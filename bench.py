@@ -218,6 +218,11 @@ def main():
                 "executed_mad_frac_of_peak": ach * 74.0 / 136.0 / PEAK_TMAD,
                 "traffic": None,
             }
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (not live)
+                t = json.load(open(tf))
+                line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = t["source"]
         if world == 1:
             if a.cpu_sample > 0:
                 line["cpu_baseline"] = cpu_baseline(sc, pts, n_bits, min(a.cpu_sample, B), got)
