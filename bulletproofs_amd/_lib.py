@@ -170,6 +170,11 @@ class Engine:
         self._check(self.lib.bp_point_mul(self.h, scalars, points, n, out), "bp_point_mul")
         return out.raw
 
+    def add_raw(self, a, b, n):
+        out = ctypes.create_string_buffer(64 * n)
+        self._check(self.lib.bp_point_add(self.h, a, b, n, out), "bp_point_add")
+        return out.raw
+
     def msm_raw(self, scalars, points, n):
         out = ctypes.create_string_buffer(64)
         self._check(self.lib.bp_msm(self.h, scalars, points, n, out), "bp_msm")

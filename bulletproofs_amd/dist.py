@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+* MSM (`sumExps`, Utils.hs:76-80): contiguous point ranges per rank, one local Pippenger each,
+  then ONE tiny exchange - an all-gather of the 64-byte affine partial sums - and world-1 point
+  additions.  Payload is world*64 bytes, so latency, not xGMI bandwidth, is what matters.
+* Batch verification (`map verifyProof`): proofs are independent, each rank verifies its own
+  slice; the only exchange is the gather of verdict bytes.
+Nothing here touches the oracle or has a CPU fallback: `eng` is a bulletproofs_amd.Engine.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous [lo, hi) of n items for `rank` of `world` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _device(group):
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else \
+        torch.device("cpu")
+
+
+def sharded_msm(eng, scalars, points, n, group=None):
+    """sum_i scalars[i]*points[i] over all ranks' data: `scalars`/`points` are the FULL encoded
+    arrays (32/64 bytes per entry); every rank computes its range and all ranks return the sum."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n, rank, world)
+    part = eng.msm_raw(scalars[32 * lo:32 * hi], points[64 * lo:64 * hi], hi - lo)
+    dev = _device(group)
+    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
+    parts = [torch.empty(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    acc = bytes(parts[0].cpu().numpy())
+    for p in parts[1:]:
+        acc = eng.add_raw(acc, bytes(p.cpu().numpy()), 1)
+    return acc
+
+
+def sharded_verify(eng, n_bits, m, batch, scalars, points, group=None):
+    """verdicts for `batch` proofs (numpy SoA arrays scalars[5,B,32], points[rows,B,64]); each rank
+    verifies its contiguous slice and all ranks return all verdicts."""
+    import numpy as np
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(batch, rank, world)
+    sc = np.ascontiguousarray(scalars[:, lo:hi])
+    pt = np.ascontiguousarray(points[:, lo:hi])
+    mine = np.frombuffer(bytes(bytearray(int(b) for b in eng.verify_batch(n_bits, m, hi - lo, sc.tobytes(),
+                                                                          pt.tobytes()))), dtype=np.uint8) \
+        if hi > lo else np.zeros(0, dtype=np.uint8)
+    dev = _device(group)
+    width = -(-batch // world)
+    buf = torch.zeros(width, dtype=torch.uint8, device=dev)
+    buf[:hi - lo] = torch.from_numpy(mine.copy()).to(dev)
+    parts = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    out = []
+    for r, p in enumerate(parts):
+        a, b = shard_range(batch, r, world)
+        out.append(p[:b - a].cpu().numpy())
+    return np.concatenate(out)

@@ -1,0 +1,82 @@
+"""Worker of tests/test_dist.py: one rank of a world_size-2 gloo job exercising
+bulletproofs_amd.dist with a stand-in engine (the oracle plays the GPU: this test covers the
+sharding / collective plumbing on CPU, the kernels have their own GPU tests)."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bp_oracle as o  # noqa: E402
+from bulletproofs_amd import _lib, dist as bpdist  # noqa: E402
+
+
+class OracleEngine:
+    """Same byte-level surface as bulletproofs_amd.Engine for the calls dist.py makes."""
+
+    def msm_raw(self, scalars, points, n):
+        return _lib.enc_point(o.sum_exps(_lib.dec_scalars(scalars, n), _lib.dec_points(points, n)))
+
+    def add_raw(self, a, b, n):
+        return _lib.enc_points([o.point_add(x, y) for x, y in zip(_lib.dec_points(a, n), _lib.dec_points(b, n))])
+
+    def verify_batch(self, n_bits, m, batch, scalars, points):
+        sc = np.frombuffer(scalars, dtype=np.uint8).reshape(5, batch, 32)
+        k = (n_bits * m).bit_length() - 1
+        pt = np.frombuffer(points, dtype=np.uint8).reshape(4 + 2 * k + m, batch, 64)
+        out = []
+        for p in range(batch):
+            s = [_lib.dec_scalar(bytes(sc[r, p])) for r in range(5)]
+            q = [_lib.dec_point(bytes(pt[r, p])) for r in range(4 + 2 * k + m)]
+            pr = dict(tBlinding=s[0], mu=s[1], t=s[2], aCommit=q[0], sCommit=q[1], t1Commit=q[2], t2Commit=q[3],
+                      productProof=dict(lCommits=q[4:4 + k], rCommits=q[4 + k:4 + 2 * k], l=s[3], r=s[4]))
+            out.append(o.mrp_verify_proof(2**n_bits, q[4 + 2 * k:], pr))
+        return out
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    eng = OracleEngine()
+    rng = random.Random(5)  # same data on every rank
+    # --- MSM sharded over point ranges ---
+    n = 11
+    ps = [o.point_mul(o.GEN, rng.randrange(1, o.R)) for _ in range(n)]
+    es = [rng.randrange(o.R) for _ in range(n)]
+    got = _lib.dec_point(bpdist.sharded_msm(eng, _lib.enc_scalars(es), _lib.enc_points(ps), n))
+    assert got == o.sum_exps(es, ps), "sharded MSM mismatch on rank %d" % rank
+    assert bpdist.shard_range(11, 0, 2) == (0, 6) and bpdist.shard_range(11, 1, 2) == (6, 11)
+    # --- proofs sharded over ranks ---
+    nb, B = 2, 5
+    proofs, vcs = [], []
+    for i in range(B):
+        v, g = rng.randrange(4), rng.randrange(1, o.R)
+        pr = o.mrp_generate_proof(4, [(v, g)], *o.draw_blinders(rng, nb))
+        if i == 3:
+            pr["t"] = (pr["t"] + 1) % o.R
+        proofs.append(pr)
+        vcs.append(o.commit(v, g))
+    k = 1
+    sc = np.zeros((5, B, 32), dtype=np.uint8)
+    pt = np.zeros((4 + 2 * k + 1, B, 64), dtype=np.uint8)
+    for p, pr in enumerate(proofs):
+        ipp = pr["productProof"]
+        for r, s in enumerate([pr["tBlinding"], pr["mu"], pr["t"], ipp["l"], ipp["r"]]):
+            sc[r, p] = np.frombuffer(_lib.enc_scalar(s), dtype=np.uint8)
+        rows = [pr["aCommit"], pr["sCommit"], pr["t1Commit"], pr["t2Commit"]] + ipp["lCommits"] + ipp["rCommits"] + [vcs[p]]
+        for r, q in enumerate(rows):
+            pt[r, p] = np.frombuffer(_lib.enc_point(q), dtype=np.uint8)
+    v = bpdist.sharded_verify(eng, nb, 1, B, sc, pt)
+    assert v.tolist() == [1, 1, 1, 0, 1], "sharded verify mismatch on rank %d: %s" % (rank, v.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()
