@@ -189,9 +189,10 @@ BP_HD bool xyzz_eq(const xyzz& p, const xyzz& q) {
 // (The shape of the reference's `mul`; used for one-off products and tests.)
 BP_HD xyzz xyzz_mul_affine(const affine& p, const u256& k) {
   xyzz acc = xyzz_inf();
+  u256 kk = k;
   for (int i = 255; i >= 0; i--) {
     acc = xyzz_dbl(acc);
-    if (u256_bit(k, i)) acc = xyzz_madd(acc, p);
+    if (u256_pop_msb(kk)) acc = xyzz_madd(acc, p);
   }
   return acc;
 }

@@ -82,6 +82,15 @@ BP_HD bool u256_geq(const u256& a, const u256& b) {
   return u256_sub(t, a, b) == 0;
 }
 BP_HD uint32_t u256_bit(const u256& a, int i) { return (a.v[i >> 5] >> (i & 31)) & 1u; }
+// Most significant bit first, without indexing limbs by a runtime value (keeps the value in
+// registers on the GPU): returns bit 255 and shifts the value left by one.
+BP_HD uint32_t u256_pop_msb(u256& a) {
+  uint32_t top = a.v[7] >> 31;
+#pragma unroll
+  for (int i = 7; i > 0; i--) a.v[i] = (a.v[i] << 1) | (a.v[i - 1] >> 31);
+  a.v[0] <<= 1;
+  return top;
+}
 
 // acc(64) + ext(32) += a*b : one v_mad_u64_u32 plus one v_addc on the device.
 BP_HD void mac96(uint64_t& acc, uint32_t& ext, uint32_t a, uint32_t b) {
@@ -486,10 +495,10 @@ struct Mont {
   static BP_HD u256 from_mont(const u256& a) { return mul(a, u256_one()); }
   // a^e, e given as plain 256-bit integer (square-and-multiply, MSB first)
   static BP_HD u256 pow(const u256& a, const u256& e) {
-    u256 r = one();
+    u256 r = one(), ee = e;
     for (int i = 255; i >= 0; i--) {
       r = sqr(r);
-      if (u256_bit(e, i)) r = mul(r, a);
+      if (u256_pop_msb(ee)) r = mul(r, a);
     }
     return r;
   }

@@ -1,0 +1,154 @@
+// Variable-base scalar multiplication for the verifier's non-generator points
+// (L_k, R_k, S, V_j, T1, T2; /root/reference/Bulletproofs/InnerProductProof/Verifier.hs:49,
+// MultiRangeProof/Verifier.hs:59-65, RangeProof/Internal.hs:185), replacing the reference's
+// per-term double-and-add `mul`.
+//
+// secp256k1 has the endomorphism phi(x, y) = (beta*x, y) = lambda*(x, y).  A scalar k is split
+// as k = k1 + k2*lambda (mod r) with |k1|, |k2| < 2^128, so k*P = k1*P + k2*phi(P) needs 128
+// doublings instead of 256.  Up to four half-length terms share one doubling chain through a
+// joint table of all their subset sums (Straus): one table addition per bit.
+// The group element computed is exactly k*P (+ ...); only the evaluation order differs.
+#pragma once
+#include "ec.h"
+
+namespace bp {
+
+struct GlvHalf {
+  uint32_t m[5];  // magnitude, < 2^129 (proven < 2^128; one spare bit is carried)
+  bool neg;
+};
+
+BP_HD u256 glv_const(const uint32_t (&t)[8]) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return r;
+}
+
+// round(k * g / 2^384) for 256-bit k, g
+BP_HD u256 glv_mul_shift_384(const u256& k, const u256& g) {
+  uint32_t t[16];
+  mul_wide(t, k, g);
+  u256 r = u256_zero();
+  uint64_t c = (t[11] >> 31) & 1u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += t[12 + i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  r.v[4] = (uint32_t)c;
+  return r;
+}
+
+// k (canonical, < r) -> (k1, k2), k = k1 + k2*lambda (mod r)
+BP_HD void glv_split(const u256& k, GlvHalf& h1, GlvHalf& h2) {
+  const uint32_t G1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+  const uint32_t G2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+  // (-b1), (-b2), lambda premultiplied by 2^256 mod r so that one Montgomery product with a plain operand gives x*c mod r
+  const uint32_t MB1_M[8] = {0x0AD9263Cu, 0xC50468D0u, 0xFAA6ED42u, 0x1B1C8205u, 0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu};
+  const uint32_t MB2_M[8] = {0x6A144696u, 0x0CAC5E50u, 0xF3BA5939u, 0x1E8A8DC5u, 0xBA244FCEu, 0x176CDF65u, 0x8E173580u, 0xC25575EBu};
+  const uint32_t LAM_M[8] = {0xC9926C9Eu, 0xF07DEB3Du, 0x83C6944Cu, 0x2C93E7ADu, 0x52697D91u, 0x73A96606u, 0x8558D639u, 0x53284017u};
+  const uint32_t HALF_N[8] = {0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu};
+  u256 c1 = glv_mul_shift_384(k, glv_const(G1));
+  u256 c2 = glv_mul_shift_384(k, glv_const(G2));
+  u256 r2 = Fr::add(Fr::mul(c1, glv_const(MB1_M)), Fr::mul(c2, glv_const(MB2_M)));
+  u256 r1 = Fr::sub(k, Fr::mul(r2, glv_const(LAM_M)));
+  u256 half = glv_const(HALF_N);
+  u256 t;
+  h1.neg = u256_sub(t, half, r1) != 0;  // r1 > (r-1)/2
+  if (h1.neg) r1 = Fr::neg(r1);
+  h2.neg = u256_sub(t, half, r2) != 0;
+  if (h2.neg) r2 = Fr::neg(r2);
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    h1.m[i] = r1.v[i];
+    h2.m[i] = r2.v[i];
+  }
+}
+
+// phi(P) = (beta * x, y)
+BP_HD affine glv_phi(const affine& p) {
+  const uint32_t BETA[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
+  affine r;
+  r.x = fq_mul(p.x, glv_const(BETA));  // (0,0) stays the identity encoding
+  r.y = p.y;
+  return r;
+}
+
+// 129-bit magnitudes as a left-aligned 160-bit shift register: top bit first
+struct BitReg {
+  uint32_t w[5];
+};
+BP_HD BitReg bitreg_init(const GlvHalf& h) {
+  BitReg b;
+  b.w[4] = (h.m[4] << 31) | (h.m[3] >> 1);
+  b.w[3] = (h.m[3] << 31) | (h.m[2] >> 1);
+  b.w[2] = (h.m[2] << 31) | (h.m[1] >> 1);
+  b.w[1] = (h.m[1] << 31) | (h.m[0] >> 1);
+  b.w[0] = h.m[0] << 31;
+  return b;
+}
+BP_HD uint32_t bitreg_next(BitReg& b) {
+  uint32_t top = b.w[4] >> 31;
+  b.w[4] = (b.w[4] << 1) | (b.w[3] >> 31);
+  b.w[3] = (b.w[3] << 1) | (b.w[2] >> 31);
+  b.w[2] = (b.w[2] << 1) | (b.w[1] >> 31);
+  b.w[1] = (b.w[1] << 1) | (b.w[0] >> 31);
+  b.w[0] <<= 1;
+  return top;
+}
+constexpr int GLV_BITS = 129;
+
+// Joint table over T signed half-terms: entry e in [1, 2^T) = sum_{j in bits(e)} q[j], XYZZ.
+// The single-term entries (e = 2^j) are stored first; every composite entry is then formed from two
+// STORED entries (the entry without its top term, and the top term read back as an affine point),
+// so the build loop has one addition site and no register-array indexing by a runtime value.
+template <int T, class Store, class Load>
+BP_HD void joint_table_build(const affine (&q)[T], Store store, Load load) {
+#pragma unroll
+  for (int j = 0; j < T; j++) store(1 << j, xyzz_from_affine(q[j]));
+#pragma unroll 1
+  for (int e = 3; e < (1 << T); e++) {
+    int top = 31 - __builtin_clz((unsigned)e);
+    int rest = e & ~(1 << top);
+    if (rest == 0) continue;  // single-term entry, already stored
+    xyzz single = load(1 << top);  // ZZ = ZZZ = 1, or the identity
+    affine qt;
+    qt.x = single.X;
+    qt.y = single.Y;
+    if (xyzz_is_inf(single)) qt = affine_inf();
+    store(e, xyzz_madd(load(rest), qt));
+  }
+}
+
+// Host-testable reference of the whole construction for up to two points:
+//   k[0]*P[0] (+ k[1]*P[1]) via GLV + one joint table in `tab` (size >= 2^(2*NP)).
+template <int NP>
+BP_HD xyzz glv_multiexp_local(const u256 (&k)[NP], const affine (&P)[NP], xyzz* tab) {
+  constexpr int T = 2 * NP;
+  affine q[T];
+  BitReg br[T];
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    GlvHalf h1, h2;
+    glv_split(k[j], h1, h2);
+    affine p1 = P[j], p2 = glv_phi(P[j]);
+    q[2 * j] = h1.neg ? affine_neg(p1) : p1;
+    q[2 * j + 1] = h2.neg ? affine_neg(p2) : p2;
+    br[2 * j] = bitreg_init(h1);
+    br[2 * j + 1] = bitreg_init(h2);
+  }
+  joint_table_build<T>(q, [&](int e, const xyzz& v) { tab[e] = v; }, [&](int e) { return tab[e]; });
+  xyzz acc = xyzz_inf();
+  for (int i = 0; i < GLV_BITS; i++) {
+    acc = xyzz_dbl(acc);
+    uint32_t idx = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) idx |= bitreg_next(br[j]) << j;
+    if (idx) acc = xyzz_add(acc, tab[idx]);
+  }
+  return acc;
+}
+
+}  // namespace bp

@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) k_add_two_mul(const uint8_t* __restrict__
   xyzz acc = xyzz_inf();
   for (int j = 255; j >= 0; j--) {
     acc = xyzz_dbl(acc);
-    if (u256_bit(k0, j)) acc = xyzz_madd(acc, a);
-    if (u256_bit(k1, j)) acc = xyzz_madd(acc, b);
+    if (u256_pop_msb(k0)) acc = xyzz_madd(acc, a);
+    if (u256_pop_msb(k1)) acc = xyzz_madd(acc, b);
   }
   st_affine(out + (size_t)i * 64, xyzz_to_affine(acc));
 }

@@ -41,7 +41,7 @@ struct bp_vbatch {
   uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
   bp::u256 *cst, *ypowinv, *zpow, *xk_m, *xkinv_m;
   uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
-  bp::xyzz *acc1, *acc2;
+  bp::xyzz *acc1, *acc2, *vtab;
   uint32_t nt1, nt3a, nt3b, npts;
   int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
   // profiling: event pairs around the three k_fixed_multiexp launches

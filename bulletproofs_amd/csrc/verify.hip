@@ -18,6 +18,7 @@
 #include "engine.h"
 #include "devio.h"
 #include "fixedbase.h"
+#include "glv.h"
 #include "verify.h"
 
 namespace bp {
@@ -143,24 +144,55 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
   if (live && sub == 0) st_xyzz(&acc_out[p], acc);
 }
 
-// ---- variable-base terms: bit-serial interleaved double-and-add ------------------------------
-// result = [acc_in] + sum_{j<nt} k_j * P_j + sum_{j<na} (+/-) Q_j
-template <int NT>
-__device__ __forceinline__ xyzz var_multiexp(const u256 k[NT], const affine P[NT]) {
-  u256 kk[NT];
+// ---- variable-base terms: GLV halves + joint (Straus) tables in global memory (glv.h) ----------
+// Table entry e (1-based) of table t for proof p lives at tab[(15*t + e - 1) * B + p].
+constexpr int VT_ENTRIES = 18;  // up to three points: one 4-term table (15) + one 2-term table (3)
+
+template <int NP>
+__device__ __forceinline__ xyzz glv_multiexp_dev(const u256 (&k)[NP], const affine (&P)[NP], xyzz* __restrict__ tab,
+                                                 size_t B, size_t p) {
+  constexpr int T = 2 * NP;
+  constexpr int T0 = T > 4 ? 4 : T;  // half-terms in table 0
+  constexpr int T1 = T - T0;         // half-terms in table 1 (0 or 2)
+  affine q[T];
+  BitReg br[T];
 #pragma unroll
-  for (int j = 0; j < NT; j++) kk[j] = k[j];
+  for (int j = 0; j < NP; j++) {
+    GlvHalf h1, h2;
+    glv_split(k[j], h1, h2);
+    affine p2 = glv_phi(P[j]);
+    q[2 * j] = h1.neg ? affine_neg(P[j]) : P[j];
+    q[2 * j + 1] = h2.neg ? affine_neg(p2) : p2;
+    br[2 * j] = bitreg_init(h1);
+    br[2 * j + 1] = bitreg_init(h2);
+  }
+  {
+    affine q0[T0];
+#pragma unroll
+    for (int j = 0; j < T0; j++) q0[j] = q[j];
+    joint_table_build<T0>(
+        q0, [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * B + p], v); },
+        [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * B + p]); });
+  }
+  if (T1 > 0) {
+    affine q1[T1 > 0 ? T1 : 1];
+#pragma unroll
+    for (int j = 0; j < T1; j++) q1[j] = q[T0 + j];
+    joint_table_build<(T1 > 0 ? T1 : 1)>(
+        q1, [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(15 + e - 1) * B + p], v); },
+        [&](int e) { return ld_xyzz(&tab[(size_t)(15 + e - 1) * B + p]); });
+  }
   xyzz acc = xyzz_inf();
-  for (int bit = 0; bit < 256; bit++) {
+#pragma unroll 1
+  for (int i = 0; i < GLV_BITS; i++) {
+    uint32_t idx0 = 0, idx1 = 0;
+#pragma unroll
+    for (int j = 0; j < T0; j++) idx0 |= bitreg_next(br[j]) << j;
+#pragma unroll
+    for (int j = 0; j < T1; j++) idx1 |= bitreg_next(br[T0 + j]) << j;
     acc = xyzz_dbl(acc);
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-      uint32_t top = kk[j].v[7] >> 31;
-#pragma unroll
-      for (int i = 7; i > 0; i--) kk[j].v[i] = (kk[j].v[i] << 1) | (kk[j].v[i - 1] >> 31);
-      kk[j].v[0] <<= 1;
-      if (top) acc = xyzz_madd(acc, P[j]);
-    }
+    if (idx0) acc = xyzz_add(acc, ld_xyzz(&tab[(size_t)(idx0 - 1) * B + p]));
+    if (T1 > 0 && idx1) acc = xyzz_add(acc, ld_xyzz(&tab[(size_t)(15 + idx1 - 1) * B + p]));
   }
   return acc;
 }
@@ -168,13 +200,13 @@ __device__ __forceinline__ xyzz var_multiexp(const u256 k[NT], const affine P[NT
 // stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported)
 __global__ void __launch_bounds__(256) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
                                                     const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
-                                                    uint8_t* __restrict__ acc_aff /*[B][64]*/) {
+                                                    xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
   u256 k[1] = {Fr::from_mont(ldm(cst, C_X * B + p))};
   affine P[1] = {ld_affine(pts + ((size_t)VP_S * B + p) * 64)};
-  xyzz acc = var_multiexp<1>(k, P);
+  xyzz acc = glv_multiexp_dev<1>(k, P, tab, B, p);
   acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
   acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
   st_affine(acc_aff + (size_t)p * 64, xyzz_to_affine(acc));
@@ -184,7 +216,7 @@ __global__ void __launch_bounds__(256) k_stage1_tail(VDims d, const uint8_t* __r
 __global__ void __launch_bounds__(256) k_round(VDims d, uint32_t round, const uint8_t* __restrict__ pts,
                                               const uint8_t* __restrict__ xk /*[B][32] canonical*/,
                                               u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
-                                              uint8_t* __restrict__ acc_aff) {
+                                              xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
@@ -195,7 +227,7 @@ __global__ void __launch_bounds__(256) k_round(VDims d, uint32_t round, const ui
   u256 k[2] = {Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv))};
   affine P[2] = {ld_affine(pts + ((size_t)(VP_L0 + round) * B + p) * 64),
                  ld_affine(pts + ((size_t)(VP_L0 + d.k + round) * B + p) * 64)};
-  xyzz acc = var_multiexp<2>(k, P);
+  xyzz acc = glv_multiexp_dev<2>(k, P, tab, B, p);
   acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
   st_affine(acc_aff + (size_t)p * 64, xyzz_to_affine(acc));
 }
@@ -249,7 +281,8 @@ __global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restri
 // V_0..V_{m-1}, T1, T2); the list length m + 2 is even for every power-of-two m >= 2 and 3 for m = 1.
 template <int NT>
 __global__ void __launch_bounds__(256) k_var_terms(VDims d, uint32_t j0, const uint8_t* __restrict__ pts,
-                                                  const uint8_t* __restrict__ vs, xyzz* __restrict__ acc2) {
+                                                  const uint8_t* __restrict__ vs, xyzz* __restrict__ tab,
+                                                  xyzz* __restrict__ acc2) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
@@ -263,7 +296,7 @@ __global__ void __launch_bounds__(256) k_var_terms(VDims d, uint32_t j0, const u
     uint32_t row = term < d.m ? VP_L0 + 2 * d.k + term : (term == d.m ? VP_T1 : VP_T2);
     P[j] = ld_affine(pts + ((size_t)row * B + p) * 64);
   }
-  xyzz acc = var_multiexp<NT>(k, P);
+  xyzz acc = glv_multiexp_dev<NT>(k, P, tab, B, p);
   acc = xyzz_add(acc, ld_xyzz(&acc2[p]));
   st_xyzz(&acc2[p], acc);
 }
@@ -322,7 +355,7 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   prof_begin(vb, 0, vb->nt1);
   hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt1, lpp, vb->dig1, vb->tb1, ctx->d_table, vb->acc1);
   prof_end(vb, 0);
-  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->acc_aff);
+  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff);
   BP_TRY(hipGetLastError());
   BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
@@ -338,7 +371,7 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   VDims d = vb->d;
   size_t B = d.B;
   BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, vb->stream));
-  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->acc_aff);
+  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff);
   BP_TRY(hipGetLastError());
   BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage++;
@@ -367,10 +400,10 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
   uint32_t nv = d.m + 2;
   uint32_t j = 0;
   if (nv & 1u) {  // m = 1: three terms, one pass of three
-    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID(B), d, 0u, vb->pts, vb->vs, vb->acc2);
+    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID(B), d, 0u, vb->pts, vb->vs, vb->vtab, vb->acc2);
     j = 3;
   }
-  for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->acc2);
+  for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->vtab, vb->acc2);
   hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict);
   BP_TRY(hipGetLastError());
   BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
@@ -449,6 +482,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->tb3b = c.take<uint32_t>(vb->nt3b);
     vb->acc1 = c.take<xyzz>(B);
     vb->acc2 = c.take<xyzz>(B);
+    vb->vtab = c.take<xyzz>((size_t)VT_ENTRIES * B);
     return c.off;
   };
   size_t need = carve(nullptr);

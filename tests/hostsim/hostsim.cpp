@@ -106,3 +106,27 @@ extern "C" void hs_msm(const uint8_t* scalars, const uint8_t* points, size_t n, 
   xyzz r = window_combine(pl, [&](int w) { return wsum[w]; });
   sta(out, xyzz_to_affine(r));
 }
+
+// ---- GLV decomposition + joint-table multi-exponentiation (glv.h) ----------------------------
+#include "../../bulletproofs_amd/csrc/glv.h"
+// out1/out2: 32-byte magnitudes, signs in sgn[0], sgn[1]
+extern "C" void hs_glv_split(const uint8_t* k, uint8_t* out1, uint8_t* out2, uint8_t* sgn) {
+  GlvHalf h1, h2;
+  glv_split(ld(k), h1, h2);
+  memset(out1, 0, 32); memset(out2, 0, 32);
+  memcpy(out1, h1.m, 20); memcpy(out2, h2.m, 20);
+  sgn[0] = h1.neg; sgn[1] = h2.neg;
+}
+// np = 1: k0*P0 ; np = 2: k0*P0 + k1*P1
+extern "C" void hs_glv_multiexp(int np, const uint8_t* ks, const uint8_t* ps, uint8_t* out) {
+  xyzz tab[16];
+  xyzz r;
+  if (np == 1) {
+    u256 k[1] = {ld(ks)}; affine P[1] = {lda(ps)};
+    r = glv_multiexp_local<1>(k, P, tab);
+  } else {
+    u256 k[2] = {ld(ks), ld(ks + 32)}; affine P[2] = {lda(ps), lda(ps + 64)};
+    r = glv_multiexp_local<2>(k, P, tab);
+  }
+  sta(out, xyzz_to_affine(r));
+}
