@@ -100,14 +100,13 @@ BP_HD uint32_t bitreg_next(BitReg& b) {
 }
 constexpr int GLV_BITS = 129;
 
-// Joint table over T signed half-terms: entry e in [1, 2^T) = sum_{j in bits(e)} q[j], XYZZ.
-// The single-term entries (e = 2^j) are stored first; every composite entry is then formed from two
-// STORED entries (the entry without its top term, and the top term read back as an affine point),
-// so the build loop has one addition site and no register-array indexing by a runtime value.
+// Joint table over T signed half-terms q[0..T): entry e in [1, 2^T) = sum_{j in bits(e)} q[j], XYZZ.
+// The caller stores the single-term entries (e = 2^j) with xyzz_from_affine(q[j]); this routine then
+// forms every composite entry from two STORED entries (the entry without its top term, and the top
+// term read back as an affine point), so the loop has one addition site and nothing is indexed by
+// a runtime value in registers.
 template <int T, class Store, class Load>
-BP_HD void joint_table_build(const affine (&q)[T], Store store, Load load) {
-#pragma unroll
-  for (int j = 0; j < T; j++) store(1 << j, xyzz_from_affine(q[j]));
+BP_HD void joint_table_composites(Store store, Load load) {
 #pragma unroll 1
   for (int e = 3; e < (1 << T); e++) {
     int top = 31 - __builtin_clz((unsigned)e);
@@ -122,30 +121,38 @@ BP_HD void joint_table_build(const affine (&q)[T], Store store, Load load) {
   }
 }
 
-// Host-testable reference of the whole construction for up to two points:
-//   k[0]*P[0] (+ k[1]*P[1]) via GLV + one joint table in `tab` (size >= 2^(2*NP)).
+// Split k, store +-P and +-phi(P) as the single-term entries ea, eb and return their bit streams.
+struct HalfPair {
+  BitReg a, b;
+};
+template <class Store>
+BP_HD HalfPair glv_prep_point(const u256& k, const affine& P, int ea, int eb, Store store) {
+  GlvHalf h1, h2;
+  glv_split(k, h1, h2);
+  affine p2 = glv_phi(P);
+  store(ea, xyzz_from_affine(h1.neg ? affine_neg(P) : P));
+  store(eb, xyzz_from_affine(h2.neg ? affine_neg(p2) : p2));
+  HalfPair hp;
+  hp.a = bitreg_init(h1);
+  hp.b = bitreg_init(h2);
+  return hp;
+}
+
+// Host-testable reference of the whole construction for one or two points:
+//   k[0]*P[0] (+ k[1]*P[1]) via GLV + one joint table in `tab` (size >= 16).
 template <int NP>
 BP_HD xyzz glv_multiexp_local(const u256 (&k)[NP], const affine (&P)[NP], xyzz* tab) {
-  constexpr int T = 2 * NP;
-  affine q[T];
-  BitReg br[T];
-#pragma unroll
-  for (int j = 0; j < NP; j++) {
-    GlvHalf h1, h2;
-    glv_split(k[j], h1, h2);
-    affine p1 = P[j], p2 = glv_phi(P[j]);
-    q[2 * j] = h1.neg ? affine_neg(p1) : p1;
-    q[2 * j + 1] = h2.neg ? affine_neg(p2) : p2;
-    br[2 * j] = bitreg_init(h1);
-    br[2 * j + 1] = bitreg_init(h2);
-  }
-  joint_table_build<T>(q, [&](int e, const xyzz& v) { tab[e] = v; }, [&](int e) { return tab[e]; });
+  auto store = [&](int e, const xyzz& v) { tab[e] = v; };
+  auto load = [&](int e) { return tab[e]; };
+  HalfPair h0 = glv_prep_point(k[0], P[0], 1, 2, store);
+  HalfPair h1 = h0;
+  if (NP == 2) h1 = glv_prep_point(k[NP - 1], P[NP - 1], 4, 8, store);
+  joint_table_composites<2 * NP>(store, load);
   xyzz acc = xyzz_inf();
   for (int i = 0; i < GLV_BITS; i++) {
     acc = xyzz_dbl(acc);
-    uint32_t idx = 0;
-#pragma unroll
-    for (int j = 0; j < T; j++) idx |= bitreg_next(br[j]) << j;
+    uint32_t idx = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1);
+    if (NP == 2) idx |= (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
     if (idx) acc = xyzz_add(acc, tab[idx]);
   }
   return acc;

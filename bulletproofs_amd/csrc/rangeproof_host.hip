@@ -8,6 +8,7 @@
 // and ping-pongs with the GPU: the batch is cut into chunks, and while the GPU
 // runs one chunk's round the host hashes the other chunk's transcript.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -235,9 +236,16 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
   const ShowStyle st = job->style;
   const uint32_t k = job->k;
   int rc;
+  // BP_TRACE=1: print a host-side timeline (ms since entry) of hashing / waiting per chunk
+  static const bool trace = getenv("BP_TRACE") != nullptr;
+  auto t_entry = std::chrono::steady_clock::now();
+  auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
+#define TRACE(what, c, r, t0) do { if (trace) fprintf(stderr, "[vjob] %-8s chunk %d round %d  %8.3f -> %8.3f ms\n", what, (int)(c), (int)(r), t0, now_ms()); } while (0)
+  int cidx = 0;
   // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
   for (auto& ch : job->chunks) {
     const size_t B = ch.B;
+    double t_h = now_ms();
     job->pool->run(
         [&](size_t a, size_t b) {
           uint8_t buf[MSG_SCRATCH];
@@ -282,13 +290,19 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
           }
         },
         B);
+    TRACE("hash0", cidx, -1, t_h);
+    cidx++;
     if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc)) != BP_OK) return rc;
   }
   // mkChallenges (InnerProductProof/Verifier.hs:44-53)
   for (uint32_t r = 0; r < k; r++) {
+    cidx = 0;
     for (auto& ch : job->chunks) {
       const size_t B = ch.B;
+      double t_w = now_ms();
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
+      TRACE("wait", cidx, r, t_w);
+      double t_h = now_ms();
       job->pool->run(
           [&](size_t a, size_t b) {
             uint8_t buf[MSG_SCRATCH];
@@ -303,9 +317,12 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
             }
           },
           B);
+      TRACE("hashR", cidx, r, t_h);
+      cidx++;
       if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc)) != BP_OK) return rc;
     }
   }
+  double t_f = now_ms();
   for (auto& ch : job->chunks) {
     if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
     if ((rc = vbatch_finish_async(ch.vb, ch.verdict)) != BP_OK) return rc;
@@ -314,6 +331,8 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
     if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
     memcpy(verdicts + ch.first, ch.verdict, ch.B);
   }
+  TRACE("final", -1, -1, t_f);
+#undef TRACE
   return BP_OK;
 }
 

@@ -12,6 +12,7 @@
 // implemented; SHOW_DERIVED ("A (P x) (P y)", "P s") is the default.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #if defined(__x86_64__)
 #include <cpuid.h>
@@ -61,6 +62,14 @@ static inline void sha256_blocks_portable(uint32_t st[8], const uint8_t* p, size
 }
 
 #if defined(__x86_64__)
+#define BP_SHA_QROUND(M, KOFF)                                               \
+  msg = _mm_add_epi32(M, _mm_loadu_si128((const __m128i*)&SHA_K[KOFF]));     \
+  s1 = _mm_sha256rnds2_epu32(s1, s0, msg);                                   \
+  msg = _mm_shuffle_epi32(msg, 0x0E);                                        \
+  s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
+#define BP_SHA_SCHED(W0, W1, W2, W3) \
+  W0 = _mm_sha256msg2_epu32(_mm_add_epi32(_mm_sha256msg1_epu32(W0, W1), _mm_alignr_epi8(W3, W2, 4)), W3);
+
 __attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_shani(uint32_t st[8], const uint8_t* p,
                                                                                     size_t nblk) {
   const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
@@ -71,22 +80,27 @@ __attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_sha
   __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                  // ABEF
   s1 = _mm_blend_epi16(s1, tmp, 0xF0);                       // CDGH
   for (; nblk; nblk--, p += 64) {
-    __m128i abef = s0, cdgh = s1;
-    __m128i m[4];
-    for (int i = 0; i < 4; i++) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16 * i)), MASK);
-    for (int r = 0; r < 16; r++) {
-      __m128i msg = _mm_add_epi32(m[r & 3], _mm_loadu_si128((const __m128i*)&SHA_K[4 * r]));
-      s1 = _mm_sha256rnds2_epu32(s1, s0, msg);
-      msg = _mm_shuffle_epi32(msg, 0x0E);
-      s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
-      if (r < 12) {
-        // schedule W[4(r+4) .. 4(r+4)+3] into m[r & 3]
-        __m128i w0 = m[r & 3], w1 = m[(r + 1) & 3], w2 = m[(r + 2) & 3], w3 = m[(r + 3) & 3];
-        __m128i t = _mm_sha256msg1_epu32(w0, w1);
-        t = _mm_add_epi32(t, _mm_alignr_epi8(w3, w2, 4));
-        m[r & 3] = _mm_sha256msg2_epu32(t, w3);
-      }
-    }
+    __m128i abef = s0, cdgh = s1, msg;
+    __m128i m0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 0)), MASK);
+    __m128i m1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16)), MASK);
+    __m128i m2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 32)), MASK);
+    __m128i m3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 48)), MASK);
+    BP_SHA_QROUND(m0, 0)  BP_SHA_SCHED(m0, m1, m2, m3)
+    BP_SHA_QROUND(m1, 4)  BP_SHA_SCHED(m1, m2, m3, m0)
+    BP_SHA_QROUND(m2, 8)  BP_SHA_SCHED(m2, m3, m0, m1)
+    BP_SHA_QROUND(m3, 12) BP_SHA_SCHED(m3, m0, m1, m2)
+    BP_SHA_QROUND(m0, 16) BP_SHA_SCHED(m0, m1, m2, m3)
+    BP_SHA_QROUND(m1, 20) BP_SHA_SCHED(m1, m2, m3, m0)
+    BP_SHA_QROUND(m2, 24) BP_SHA_SCHED(m2, m3, m0, m1)
+    BP_SHA_QROUND(m3, 28) BP_SHA_SCHED(m3, m0, m1, m2)
+    BP_SHA_QROUND(m0, 32) BP_SHA_SCHED(m0, m1, m2, m3)
+    BP_SHA_QROUND(m1, 36) BP_SHA_SCHED(m1, m2, m3, m0)
+    BP_SHA_QROUND(m2, 40) BP_SHA_SCHED(m2, m3, m0, m1)
+    BP_SHA_QROUND(m3, 44) BP_SHA_SCHED(m3, m0, m1, m2)
+    BP_SHA_QROUND(m0, 48)
+    BP_SHA_QROUND(m1, 52)
+    BP_SHA_QROUND(m2, 56)
+    BP_SHA_QROUND(m3, 60)
     s0 = _mm_add_epi32(s0, abef);
     s1 = _mm_add_epi32(s1, cdgh);
   }
@@ -97,11 +111,14 @@ __attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_sha
   _mm_storeu_si128((__m128i*)&st[0], s0);
   _mm_storeu_si128((__m128i*)&st[4], s1);
 }
+#undef BP_SHA_QROUND
+#undef BP_SHA_SCHED
 static inline bool cpu_has_shani() {
   static int cached = -1;
   if (cached < 0) {
     unsigned a, b, c, d;
     cached = (__get_cpuid_count(7, 0, &a, &b, &c, &d) && (b & (1u << 29))) ? 1 : 0;
+    if (getenv("BP_NO_SHANI")) cached = 0;  // test hook: force the portable path
   }
   return cached == 1;
 }
@@ -168,6 +185,9 @@ static inline size_t u256_to_dec(const uint8_t le[32], char* out) {
     chunk[nchunk++] = rem;
     while (top >= 0 && v[top] == 0) top--;
   }
+  static const char D2[201] =
+      "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960"
+      "616263646566676869707172737475767778798081828384858687888990919293949596979899";
   char* o = out;
   // most significant chunk without leading zeros
   {
@@ -180,12 +200,30 @@ static inline size_t u256_to_dec(const uint8_t le[32], char* out) {
     } while (c);
     while (n) *o++ = tmp[--n];
   }
+  // every further chunk is exactly 19 digits: 1 + 9 pairs
   for (int k = nchunk - 2; k >= 0; k--) {
     uint64_t c = chunk[k];
-    for (int i = 18; i >= 0; i--) {
-      o[i] = (char)('0' + c % 10);
-      c /= 10;
+    uint32_t lo9 = (uint32_t)(c % 1000000000ULL);
+    uint64_t hi = c / 1000000000ULL;          // 10 digits
+    uint32_t mid9 = (uint32_t)(hi % 1000000000ULL);
+    o[0] = (char)('0' + (uint32_t)(hi / 1000000000ULL));
+    // 9 digits = 1 + 4 pairs, twice
+    uint32_t v = mid9;
+    for (int i = 4; i >= 1; i--) {
+      uint32_t q = v / 100, r2 = v - q * 100;
+      o[2 * i] = D2[2 * r2];
+      o[2 * i + 1] = D2[2 * r2 + 1];
+      v = q;
     }
+    o[1] = (char)('0' + v);
+    v = lo9;
+    for (int i = 4; i >= 1; i--) {
+      uint32_t q = v / 100, r2 = v - q * 100;
+      o[9 + 2 * i] = D2[2 * r2];
+      o[9 + 2 * i + 1] = D2[2 * r2 + 1];
+      v = q;
+    }
+    o[10] = (char)('0' + v);
     o += 19;
   }
   return (size_t)(o - out);

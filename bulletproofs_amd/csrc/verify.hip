@@ -151,54 +151,34 @@ constexpr int VT_ENTRIES = 18;  // up to three points: one 4-term table (15) + o
 template <int NP>
 __device__ __forceinline__ xyzz glv_multiexp_dev(const u256 (&k)[NP], const affine (&P)[NP], xyzz* __restrict__ tab,
                                                  size_t B, size_t p) {
-  constexpr int T = 2 * NP;
-  constexpr int T0 = T > 4 ? 4 : T;  // half-terms in table 0
-  constexpr int T1 = T - T0;         // half-terms in table 1 (0 or 2)
-  affine q[T];
-  BitReg br[T];
-#pragma unroll
-  for (int j = 0; j < NP; j++) {
-    GlvHalf h1, h2;
-    glv_split(k[j], h1, h2);
-    affine p2 = glv_phi(P[j]);
-    q[2 * j] = h1.neg ? affine_neg(P[j]) : P[j];
-    q[2 * j + 1] = h2.neg ? affine_neg(p2) : p2;
-    br[2 * j] = bitreg_init(h1);
-    br[2 * j + 1] = bitreg_init(h2);
-  }
-  {
-    affine q0[T0];
-#pragma unroll
-    for (int j = 0; j < T0; j++) q0[j] = q[j];
-    joint_table_build<T0>(
-        q0, [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * B + p], v); },
-        [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * B + p]); });
-  }
-  if (T1 > 0) {
-    affine q1[T1 > 0 ? T1 : 1];
-#pragma unroll
-    for (int j = 0; j < T1; j++) q1[j] = q[T0 + j];
-    joint_table_build<(T1 > 0 ? T1 : 1)>(
-        q1, [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(15 + e - 1) * B + p], v); },
-        [&](int e) { return ld_xyzz(&tab[(size_t)(15 + e - 1) * B + p]); });
-  }
+  // table 0: points 0 (and 1); table 1 (entries 16..18): point 2
+  auto store0 = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * B + p], v); };
+  auto load0 = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * B + p]); };
+  auto store1 = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(15 + e - 1) * B + p], v); };
+  auto load1 = [&](int e) { return ld_xyzz(&tab[(size_t)(15 + e - 1) * B + p]); };
+  HalfPair h0 = glv_prep_point(k[0], P[0], 1, 2, store0);
+  HalfPair h1 = h0, h2 = h0;
+  if constexpr (NP >= 2) h1 = glv_prep_point(k[1], P[1], 4, 8, store0);
+  if constexpr (NP >= 3) h2 = glv_prep_point(k[2], P[2], 1, 2, store1);
+  joint_table_composites<(NP >= 2 ? 4 : 2)>(store0, load0);
+  if constexpr (NP >= 3) joint_table_composites<2>(store1, load1);
   xyzz acc = xyzz_inf();
 #pragma unroll 1
   for (int i = 0; i < GLV_BITS; i++) {
-    uint32_t idx0 = 0, idx1 = 0;
-#pragma unroll
-    for (int j = 0; j < T0; j++) idx0 |= bitreg_next(br[j]) << j;
-#pragma unroll
-    for (int j = 0; j < T1; j++) idx1 |= bitreg_next(br[T0 + j]) << j;
+    uint32_t idx0 = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1), idx1 = 0;
+    if constexpr (NP >= 2) idx0 |= (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
+    if constexpr (NP >= 3) idx1 = bitreg_next(h2.a) | (bitreg_next(h2.b) << 1);
     acc = xyzz_dbl(acc);
-    if (idx0) acc = xyzz_add(acc, ld_xyzz(&tab[(size_t)(idx0 - 1) * B + p]));
-    if (T1 > 0 && idx1) acc = xyzz_add(acc, ld_xyzz(&tab[(size_t)(15 + idx1 - 1) * B + p]));
+    if (idx0) acc = xyzz_add(acc, load0((int)idx0));
+    if constexpr (NP >= 3) {
+      if (idx1) acc = xyzz_add(acc, load1((int)idx1));
+    }
   }
   return acc;
 }
 
 // stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported)
-__global__ void __launch_bounds__(256) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
                                                     const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
                                                     xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +193,7 @@ __global__ void __launch_bounds__(256) k_stage1_tail(VDims d, const uint8_t* __r
 }
 
 // one IPP round of mkChallenges: acc <- x^2 L + x^-2 R + acc  (Verifier.hs:47-50)
-__global__ void __launch_bounds__(256) k_round(VDims d, uint32_t round, const uint8_t* __restrict__ pts,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_round(VDims d, uint32_t round, const uint8_t* __restrict__ pts,
                                               const uint8_t* __restrict__ xk /*[B][32] canonical*/,
                                               u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
                                               xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff) {
@@ -280,7 +260,7 @@ __global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restri
 // acc2 += sum of up to 2 variable-base terms per pass (terms j0, j0+1 of the E2 list:
 // V_0..V_{m-1}, T1, T2); the list length m + 2 is even for every power-of-two m >= 2 and 3 for m = 1.
 template <int NT>
-__global__ void __launch_bounds__(256) k_var_terms(VDims d, uint32_t j0, const uint8_t* __restrict__ pts,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_var_terms(VDims d, uint32_t j0, const uint8_t* __restrict__ pts,
                                                   const uint8_t* __restrict__ vs, xyzz* __restrict__ tab,
                                                   xyzz* __restrict__ acc2) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -58,3 +58,17 @@ def test_log_base2_double_arithmetic():
         assert _lib.log_base2(2**k) == o.log_base2(2**k) == k
     for v in [1, 2, 3, 5, 1000, 2**64 - 1, 2**64 + 1, 2**53 + 1, R + 1, 3 * 2**70]:
         assert _lib.log_base2(v) == o.log_base2(v)
+
+
+def test_portable_sha_path_matches():
+    """Force the non-SHA-NI code path in a child process (BP_NO_SHANI) and compare digests."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from bulletproofs_amd import _lib; "
+            "print(_lib.transcript(0, 5, raw=bytes(range(256)) * 5), _lib.transcript(1, 6, raw=b'abc'))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, BP_NO_SHANI="1")).split()
+    raw = bytes(range(256)) * 5
+    assert int(out[0]) == int.from_bytes(hashlib.sha256(raw).digest(), "big") % R
+    assert int(out[1]) == int.from_bytes(hashlib.sha256(b"abc").digest(), "big") % P
