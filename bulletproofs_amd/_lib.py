@@ -58,6 +58,9 @@ SYMBOLS = {
     "bp_vjob_destroy": (None, [_vp]),
     "bp_vjob_load": (_int, [_vp, _u8p, _u8p]),
     "bp_vjob_run": (_int, [_vp, _u8p]),
+    "bp_ipp_prove": (_int, [_vp, ctypes.c_uint32] + [_u8p] * 10),
+    "bp_upper_bound_bits": (_int, [_u8p, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "bp_rangeproof_prove": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32] + [_u8p] * 8 + [_int, _u8p, _u8p]),
 }
 
 
@@ -250,6 +253,45 @@ class Engine:
                     "bp_rangeproof_verify_batch")
         return [b != 0 for b in out.raw]
 
+    def ipp_prove(self, gs, hs, u, P, ls, rs):
+        """IPP.generateProof (InnerProductProof/Prover.hs:17-26) -> dict(lCommits, rCommits, l, r)."""
+        n = len(ls)
+        k = max(n.bit_length() - 1, 0)
+        L = ctypes.create_string_buffer(64 * max(k, 1))
+        R_ = ctypes.create_string_buffer(64 * max(k, 1))
+        l = ctypes.create_string_buffer(32)
+        r = ctypes.create_string_buffer(32)
+        self._check(self.lib.bp_ipp_prove(self.h, n, enc_points(gs), enc_points(hs), enc_point(u), enc_point(P),
+                                          enc_scalars(ls), enc_scalars(rs), L, R_, l, r), "bp_ipp_prove")
+        return dict(lCommits=dec_points(L.raw, k), rCommits=dec_points(R_.raw, k), l=dec_scalar(l.raw),
+                    r=dec_scalar(r.raw))
+
+    def prove(self, n_bits, vs_and_blindings, s_l, s_r, a_blinding, s_blinding, t1_blinding, t2_blinding,
+              checked=True):
+        """MultiRangeProof.generateProof / generateProofUnsafe (MultiRangeProof/Prover.hs:19-123) with the
+        blinders as explicit inputs; returns the proof as the oracle's dict, or raises RangeProofError-like
+        BpError carrying .code."""
+        m = len(vs_and_blindings)
+        m2 = 1
+        while m2 < m:
+            m2 *= 2
+        k = (n_bits * m2).bit_length() - 1
+        sc = ctypes.create_string_buffer(5 * 32)
+        pts = ctypes.create_string_buffer((4 + 2 * k) * 64)
+        rc = self.lib.bp_rangeproof_prove(
+            self.h, n_bits, m, enc_scalars([v % (2**256) for v, _ in vs_and_blindings]),
+            enc_scalars([b for _, b in vs_and_blindings]), enc_scalars(s_l), enc_scalars(s_r),
+            enc_scalar(a_blinding), enc_scalar(s_blinding), enc_scalar(t1_blinding), enc_scalar(t2_blinding),
+            1 if checked else 0, sc, pts)
+        if rc != 0:
+            e = BpError("bp_rangeproof_prove failed (%d): %s" % (rc, self.lib.bp_last_error(self.h).decode()))
+            e.code = rc
+            raise e
+        s = dec_scalars(sc.raw, 5)
+        p = dec_points(pts.raw, 4 + 2 * k)
+        return dict(tBlinding=s[0], mu=s[1], t=s[2], aCommit=p[0], sCommit=p[1], t1Commit=p[2], t2Commit=p[3],
+                    productProof=dict(lCommits=p[4:4 + k], rCommits=p[4 + k:4 + 2 * k], l=s[3], r=s[4]))
+
     def vjob(self, n_bits, m, batch, n_chunks=0, host_threads=0):
         return VJob(self, n_bits, m, batch, n_chunks, host_threads)
 
@@ -262,6 +304,15 @@ def transcript(style, which, pts=(), scs=(), raw=b""):
     if rc != 0:
         raise BpError("bp_transcript failed: %d" % rc)
     return dec_scalar(out.raw)
+
+
+def upper_bound_bits(upper_bound):
+    """generateProof's validation of the upper bound -> n, or the negative error code."""
+    lib = load_library()
+    nbytes = max(1, (upper_bound.bit_length() + 7) // 8)
+    n = ctypes.c_uint32()
+    rc = lib.bp_upper_bound_bits(upper_bound.to_bytes(nbytes, "little"), nbytes, ctypes.byref(n))
+    return n.value if rc == 0 else rc
 
 
 def log_base2(upper_bound):

@@ -29,6 +29,7 @@ void bp_ctx_destroy(bp_ctx* ctx) {
   ctx->io.release();
   ctx->gen.release();
   ctx->vws.release();
+  ctx->pws.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int i = 0; i < 2; i++)
     if (ctx->msm_ev[i]) (void)hipEventDestroy(ctx->msm_ev[i]);

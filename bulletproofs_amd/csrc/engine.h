@@ -57,6 +57,7 @@ struct bp_ctx {
   bp::DevBuf io;        // staging for host-pointer entry points
   bp::DevBuf gen;       // generator tables (verifier / prover)
   bp::DevBuf vws;       // batch-verifier workspace
+  bp::DevBuf pws;       // prover workspace (IPP state, gathered MSM inputs)
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // generator state (filled by bp_ctx_set_generators); pointers into `gen`
@@ -97,4 +98,11 @@ namespace bp {
 // msm.hip
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz);
+// ipp.hip (device pointers, asynchronous on ctx->stream)
+int ipp_fold_points(bp_ctx* ctx, const uint8_t* d_lo, const uint8_t* d_hi, uint32_t n, const uint8_t s_lo[32],
+                    const uint8_t s_hi[32], xyzz* d_tab, uint8_t* d_out);
+int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, const uint8_t* d_p2, const uint8_t k0[32],
+                     const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out);
+int ipp_scale_points(bp_ctx* ctx, const uint8_t* d_pts, const uint8_t* d_scalars, uint32_t n, xyzz* d_tab,
+                     uint8_t* d_out);
 }  // namespace bp

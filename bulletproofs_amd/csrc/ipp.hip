@@ -1,0 +1,110 @@
+// Inner-product-argument prover kernels on gfx950.
+//
+// One recursion step of generateProof' (/root/reference/Bulletproofs/InnerProductProof/Prover.hs:52-92):
+//   lCommit = <l_lo, G_hi> + <r_hi, H_lo> + cL*u        (:63-67)   -> one MSM over gathered points
+//   rCommit = <l_hi, G_lo> + <r_lo, H_hi> + cR*u        (:69-73)   -> one MSM
+//   gs''_i  = xInv*G_lo_i + x*G_hi_i                     (:81)      -> k_fold_points
+//   hs''_i  = x*H_lo_i + xInv*H_hi_i                     (:82)      -> k_fold_points
+//   P'      = x^2*L + xInv^2*R + P                       (:87-92)   -> k_lincomb2_add
+// and the generator rescale hs'_i = hs_i * y^-i (MultiRangeProof/Prover.hs:107) -> k_scale_points.
+// The scalar folds ls', rs' (:84-85) and the dot products cL, cR (:60-61) are O(n) Fr work and
+// stay with the host control code (prover_host.hip).
+#include <string.h>
+#include "engine.h"
+#include "devio.h"
+#include "glv.h"
+
+namespace bp {
+
+// out[i] = s_lo * lo[i] + s_hi * hi[i]  (two scalars shared by all i): GLV + joint table, one lane per i.
+// tab: VT entries x n xyzz scratch, tab[(e-1)*n + i].
+__global__ void __launch_bounds__(256) k_fold_points(const uint8_t* __restrict__ lo, const uint8_t* __restrict__ hi,
+                                                    uint32_t n, u256 s_lo, u256 s_hi, xyzz* __restrict__ tab,
+                                                    uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * n + i], v); };
+  auto load = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * n + i]); };
+  HalfPair h0 = glv_prep_point(s_lo, ld_affine(lo + (size_t)i * 64), 1, 2, store);
+  HalfPair h1 = glv_prep_point(s_hi, ld_affine(hi + (size_t)i * 64), 4, 8, store);
+  joint_table_composites<4>(store, load);
+  xyzz acc = xyzz_inf();
+#pragma unroll 1
+  for (int b = 0; b < GLV_BITS; b++) {
+    uint32_t idx = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1) | (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
+    acc = xyzz_dbl(acc);
+    if (idx) acc = xyzz_add(acc, load((int)idx));
+  }
+  st_affine(out + (size_t)i * 64, xyzz_to_affine(acc));
+}
+
+// out = k0*p0 + k1*p1 + p2 (single group element; one lane)
+__global__ void __launch_bounds__(64) k_lincomb2_add(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
+                                                    const uint8_t* __restrict__ p2, u256 k0, u256 k1,
+                                                    xyzz* __restrict__ tab, uint8_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[e - 1], v); };
+  auto load = [&](int e) { return ld_xyzz(&tab[e - 1]); };
+  HalfPair h0 = glv_prep_point(k0, ld_affine(p0), 1, 2, store);
+  HalfPair h1 = glv_prep_point(k1, ld_affine(p1), 4, 8, store);
+  joint_table_composites<4>(store, load);
+  xyzz acc = xyzz_inf();
+#pragma unroll 1
+  for (int b = 0; b < GLV_BITS; b++) {
+    uint32_t idx = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1) | (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
+    acc = xyzz_dbl(acc);
+    if (idx) acc = xyzz_add(acc, load((int)idx));
+  }
+  acc = xyzz_madd(acc, ld_affine(p2));
+  st_affine(out, xyzz_to_affine(acc));
+}
+
+// out[i] = scalars[i] * pts[i], independent scalars (canonical, 32 B each): GLV, one lane per i
+__global__ void __launch_bounds__(256) k_scale_points(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars,
+                                                     uint32_t n, xyzz* __restrict__ tab, uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * n + i], v); };
+  auto load = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * n + i]); };
+  u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)i * 32));
+  HalfPair h0 = glv_prep_point(k, ld_affine(pts + (size_t)i * 64), 1, 2, store);
+  joint_table_composites<2>(store, load);
+  xyzz acc = xyzz_inf();
+#pragma unroll 1
+  for (int b = 0; b < GLV_BITS; b++) {
+    uint32_t idx = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1);
+    acc = xyzz_dbl(acc);
+    if (idx) acc = xyzz_add(acc, load((int)idx));
+  }
+  st_affine(out + (size_t)i * 64, xyzz_to_affine(acc));
+}
+
+int ipp_fold_points(bp_ctx* ctx, const uint8_t* d_lo, const uint8_t* d_hi, uint32_t n, const uint8_t s_lo[32],
+                    const uint8_t s_hi[32], xyzz* d_tab, uint8_t* d_out) {
+  u256 a, b;
+  memcpy(a.v, s_lo, 32);
+  memcpy(b.v, s_hi, 32);
+  hipLaunchKernelGGL(k_fold_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_lo, d_hi, n, a, b, d_tab, d_out);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, const uint8_t* d_p2, const uint8_t k0[32],
+                     const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out) {
+  u256 a, b;
+  memcpy(a.v, k0, 32);
+  memcpy(b.v, k1, 32);
+  hipLaunchKernelGGL(k_lincomb2_add, dim3(1), dim3(64), 0, ctx->stream, d_p0, d_p1, d_p2, a, b, d_tab, d_out);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+int ipp_scale_points(bp_ctx* ctx, const uint8_t* d_pts, const uint8_t* d_scalars, uint32_t n, xyzz* d_tab,
+                     uint8_t* d_out) {
+  hipLaunchKernelGGL(k_scale_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_pts, d_scalars, n, d_tab,
+                     d_out);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+}  // namespace bp

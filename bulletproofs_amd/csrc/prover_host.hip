@@ -1,0 +1,430 @@
+// Host control of the prover path, in C++ above the engine (the reference is compiled Haskell):
+//   InnerProductProof.generateProof            (/root/reference/Bulletproofs/InnerProductProof/Prover.hs:17-92)
+//   MultiRangeProof.generateProof(Unsafe)      (MultiRangeProof/Prover.hs:19-123), computeLRPolys / computeTPoly (:133-169)
+//   RangeProof.generateProof                   (RangeProof/Prover.hs:15-32)
+//   commitBitVectors                           (RangeProof/Internal.hs:126-149)
+// Every `sumExps` is one bucket MSM on the GPU over device-resident generator arrays, the
+// generator folds and hs' rescale are GLV kernels (ipp.hip); the O(nm) scalar-field vector
+// algebra, bit decomposition, validation and the Fiat-Shamir transcript stay on the host.
+// Randomness: the reference draws sL, sR, aBlinding, sBlinding, t1Blinding,
+// t2Blinding from MonadRandom in that order; here they are explicit arguments.
+#include <vector>
+
+#include "engine.h"
+#include "host_fr.h"
+#include "transcript.h"
+
+using namespace bp;
+using namespace bp::host;
+
+namespace {
+
+struct ProverWs {
+  uint8_t *G, *H;        // current generator vectors (affine), n points each
+  uint8_t *G2, *H2;      // fold outputs (ping-pong)
+  uint8_t *pts;          // gathered MSM points, up to 2n + 1
+  uint8_t *sc;           // MSM scalars, up to 2n + 1
+  uint8_t *small;        // a few single points: u, P, L, R, out
+  xyzz* tab;             // 15 * n joint-table scratch
+};
+
+int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w) {
+  auto carve = [&](void* base) {
+    Carver c(base);
+    w.G = c.take<uint8_t>((size_t)n * 64);
+    w.H = c.take<uint8_t>((size_t)n * 64);
+    w.G2 = c.take<uint8_t>((size_t)n * 64);
+    w.H2 = c.take<uint8_t>((size_t)n * 64);
+    w.pts = c.take<uint8_t>((size_t)(2 * n + 2) * 64);
+    w.sc = c.take<uint8_t>((size_t)(2 * n + 2) * 32);
+    w.small = c.take<uint8_t>(16 * 64);
+    w.tab = c.take<xyzz>((size_t)15 * (n ? n : 1));
+    return c.off;
+  };
+  size_t need = carve(nullptr);
+  if (ctx->pws.reserve(need) != 0) {
+    ctx->err = "prover workspace allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  carve(ctx->pws.p);
+  return BP_OK;
+}
+
+// MSM over [ptsA (na), ptsB (nb), single] with scalars [sa, sb, s1] -> affine result to host
+int msm3(bp_ctx* ctx, ProverWs& w, const uint8_t* dA, const std::vector<Fr4>& sa, size_t a0, const uint8_t* dB,
+         const std::vector<Fr4>& sb, size_t b0, size_t cnt, const uint8_t* d_single, const Fr4& s1, uint8_t out[64]) {
+  hipStream_t st = ctx->stream;
+  std::vector<uint8_t> sc((2 * cnt + 1) * 32);
+  for (size_t i = 0; i < cnt; i++) {
+    fr_to_bytes(sa[a0 + i], &sc[i * 32]);
+    fr_to_bytes(sb[b0 + i], &sc[(cnt + i) * 32]);
+  }
+  fr_to_bytes(s1, &sc[2 * cnt * 32]);
+  if (cnt) {
+    BP_TRY(hipMemcpyAsync(w.pts, dA, cnt * 64, hipMemcpyDeviceToDevice, st));
+    BP_TRY(hipMemcpyAsync(w.pts + cnt * 64, dB, cnt * 64, hipMemcpyDeviceToDevice, st));
+  }
+  BP_TRY(hipMemcpyAsync(w.pts + 2 * cnt * 64, d_single, 64, hipMemcpyDeviceToDevice, st));
+  BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+  uint8_t* d_out = w.small + 15 * 64;
+  int rc = msm_run(ctx, w.sc, w.pts, 2 * cnt + 1, 0, d_out, nullptr);
+  if (rc != BP_OK) return rc;
+  BP_TRY(hipMemcpyAsync(out, d_out, 64, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));  // `sc` is a host temporary
+  return BP_OK;
+}
+
+// The recursion of generateProof' on device-resident G, H (w.G, w.H hold n points each).
+// ls, rs in Montgomery form; u, P affine (host bytes).  Appends L_k, R_k (64 B each) and writes l, r.
+int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], const uint8_t P0[64],
+                   std::vector<Fr4>& ls, std::vector<Fr4>& rs, ShowStyle style, std::vector<uint8_t>& Ls,
+                   std::vector<uint8_t>& Rs, uint8_t l_out[32], uint8_t r_out[32]) {
+  hipStream_t st = ctx->stream;
+  uint8_t* d_u = w.small;
+  uint8_t* d_P = w.small + 64;
+  uint8_t* d_L = w.small + 128;
+  uint8_t* d_R = w.small + 192;
+  uint8_t* d_Pn = w.small + 256;
+  uint8_t P[64];
+  memcpy(P, P0, 64);
+  BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(d_P, P, 64, hipMemcpyHostToDevice, st));
+  BP_TRY(hipStreamSynchronize(st));
+  if (n == 0) {  // ([], []) -> InnerProductProof [] [] 0 0   (Prover.hs:42)
+    memset(l_out, 0, 32);
+    memset(r_out, 0, 32);
+    return BP_OK;
+  }
+  int rc;
+  while (n > 1) {
+    uint32_t h = n / 2;
+    Fr4 cL = fr_zero(), cR = fr_zero();
+    for (uint32_t i = 0; i < h; i++) {
+      cL = fr_add(cL, fr_mul(ls[i], rs[h + i]));  // dot lsLeft rsRight  (:60)
+      cR = fr_add(cR, fr_mul(ls[h + i], rs[i]));  // dot lsRight rsLeft  (:61)
+    }
+    uint8_t L[64], R[64];
+    // lCommit = sumExps lsLeft gsRight <> sumExps rsRight hsLeft <> (bH `mul` cL)   (:63-67)
+    if ((rc = msm3(ctx, w, w.G + (size_t)h * 64, ls, 0, w.H, rs, h, h, d_u, cL, L)) != BP_OK) return rc;
+    // rCommit = sumExps lsRight gsLeft <> sumExps rsLeft hsRight <> (bH `mul` cR)   (:69-73)
+    if ((rc = msm3(ctx, w, w.G, ls, h, w.H + (size_t)h * 64, rs, 0, h, d_u, cR, R)) != BP_OK) return rc;
+    Ls.insert(Ls.end(), L, L + 64);
+    Rs.insert(Rs.end(), R, R + 64);
+    // x = shamirX' commitmentLR lCommit rCommit   (:75)
+    uint8_t buf[MSG_SCRATCH], xb[32], xib[32], x2b[32], xi2b[32];
+    Msg mm(buf, style);
+    mm.r();
+    mm.point(L);
+    mm.point(R);
+    mm.point(P);
+    mm.finish_fr(xb);
+    Fr4 x = fr_from_bytes(xb), xi = fr_inv(x);
+    fr_to_bytes(xi, xib);
+    fr_to_bytes(fr_sqr(x), x2b);
+    fr_to_bytes(fr_sqr(xi), xi2b);
+    // gs'' = xInv*gsLeft + x*gsRight ; hs'' = x*hsLeft + xInv*hsRight   (:81-82)
+    if ((rc = ipp_fold_points(ctx, w.G, w.G + (size_t)h * 64, h, xib, xb, w.tab, w.G2)) != BP_OK) return rc;
+    if ((rc = ipp_fold_points(ctx, w.H, w.H + (size_t)h * 64, h, xb, xib, w.tab, w.H2)) != BP_OK) return rc;
+    std::swap(w.G, w.G2);
+    std::swap(w.H, w.H2);
+    // commitmentLR' = x^2 L + xInv^2 R + commitmentLR   (:87-92)
+    BP_TRY(hipMemcpyAsync(d_L, L, 64, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(d_R, R, 64, hipMemcpyHostToDevice, st));
+    if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_P, x2b, xi2b, w.tab, d_Pn)) != BP_OK) return rc;
+    BP_TRY(hipMemcpyAsync(P, d_Pn, 64, hipMemcpyDeviceToHost, st));
+    BP_TRY(hipMemcpyAsync(d_P, d_Pn, 64, hipMemcpyDeviceToDevice, st));
+    // ls' = x*lsLeft + xInv*lsRight ; rs' = xInv*rsLeft + x*rsRight   (:84-85) while the GPU folds
+    for (uint32_t i = 0; i < h; i++) {
+      ls[i] = fr_add(fr_mul(x, ls[i]), fr_mul(xi, ls[h + i]));
+      rs[i] = fr_add(fr_mul(xi, rs[i]), fr_mul(x, rs[h + i]));
+    }
+    ls.resize(h);
+    rs.resize(h);
+    BP_TRY(hipStreamSynchronize(st));
+    n = h;
+  }
+  fr_to_bytes(ls[0], l_out);
+  fr_to_bytes(rs[0], r_out);
+  return BP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// IPP.generateProof on an arbitrary base (InnerProductProof/Prover.hs:17-26).  n = 0 or a power of two.
+// Gs, Hs: n points; u (bH), P (commitmentLR): one point; ls, rs: n scalars.
+// Outputs: L, R: log2(n) points each (round order), l, r: 32 bytes each.
+int bp_ipp_prove(bp_ctx* ctx, uint32_t n, const uint8_t* Gs, const uint8_t* Hs, const uint8_t* u, const uint8_t* P,
+                 const uint8_t* ls, const uint8_t* rs, uint8_t* L_out, uint8_t* R_out, uint8_t* l_out,
+                 uint8_t* r_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (n & (n - 1)) == 0, "n must be 0 or a power of two");
+  BP_REQUIRE(n <= (1u << 20), "n too large");
+  BP_REQUIRE(u && P && l_out && r_out && (n == 0 || (Gs && Hs && ls && rs)), "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  ProverWs w;
+  int rc = carve_ws(ctx, n ? n : 1, w);
+  if (rc != BP_OK) return rc;
+  if (n) {
+    BP_TRY(hipMemcpyAsync(w.G, Gs, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
+    BP_TRY(hipMemcpyAsync(w.H, Hs, (size_t)n * 64, hipMemcpyHostToDevice, ctx->stream));
+  }
+  std::vector<Fr4> l(n), r(n);
+  for (uint32_t i = 0; i < n; i++) {
+    l[i] = fr_from_bytes(ls + (size_t)i * 32);
+    r[i] = fr_from_bytes(rs + (size_t)i * 32);
+  }
+  std::vector<uint8_t> Lv, Rv;
+  rc = ipp_prove_core(ctx, w, n, u, P, l, r, (ShowStyle)ctx->show_style, Lv, Rv, l_out, r_out);
+  if (rc != BP_OK) return rc;
+  if (!Lv.empty()) {
+    BP_REQUIRE(L_out && R_out, "null pointer");
+    memcpy(L_out, Lv.data(), Lv.size());
+    memcpy(R_out, Rv.data(), Rv.size());
+  }
+  return BP_OK;
+}
+
+// `generateProof` validation (MultiRangeProof/Prover.hs:25-38): upper_bound is a little-endian integer.
+// Returns BP_OK and n = log2(upper_bound), or BP_ERR_BOUND_TOO_LARGE / BP_ERR_N_NOT_POW2.
+int bp_upper_bound_bits(const uint8_t* upper_bound, size_t len, uint32_t* n_bits) {
+  if (!upper_bound || !n_bits) return BP_ERR_ARG;
+  // upperBound < _r ?
+  uint8_t ub[40] = {0};
+  size_t top = len;
+  while (top > 0 && upper_bound[top - 1] == 0) top--;
+  if (top > 32) return BP_ERR_BOUND_TOO_LARGE;
+  memcpy(ub, upper_bound, top);
+  uint64_t v[4];
+  memcpy(v, ub, 32);
+  if (fr_geq_m(v)) return BP_ERR_BOUND_TOO_LARGE;
+  // isLogBase2 upperBound, then isLogBase2 n   (Utils.hs:87-100)
+  int bits = 0, ones = 0;
+  for (int i = 0; i < 256; i++)
+    if ((v[i >> 6] >> (i & 63)) & 1) {
+      ones++;
+      bits = i;
+    }
+  if (ones != 1) return BP_ERR_N_NOT_POW2;
+  uint32_t n = (uint32_t)bits;
+  if (n == 0 || (n & (n - 1)) != 0) return BP_ERR_N_NOT_POW2;
+  *n_bits = n;
+  return BP_OK;
+}
+
+// MultiRangeProof.generateProof (checked = 1) / generateProofUnsafe (checked = 0) for m values of n_bits bits.
+// values, blindings: m x 32 B.  sL, sR: n_bits * m2 scalars each (m2 = m padded to a power of two with (0, 0),
+// Prover.hs:41-43); alpha = aBlinding, rho = sBlinding, tau1, tau2 = t1Blinding, t2Blinding.
+// proof_scalars: 5 x 32 B (tBlinding, mu, t, l, r); proof_points: (4 + 2k) x 64 B (A, S, T1, T2, L.., R..),
+// k = log2(n_bits * m2).  Returns BP_ERR_NOT_IN_RANGE when checked and some value >= 2^n_bits.
+int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t* values, const uint8_t* blindings,
+                        const uint8_t* sL, const uint8_t* sR, const uint8_t* alpha, const uint8_t* rho,
+                        const uint8_t* tau1, const uint8_t* tau2, int checked, uint8_t* proof_scalars,
+                        uint8_t* proof_points) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(values && blindings && sL && sR && alpha && rho && tau1 && tau2 && proof_scalars && proof_points,
+             "null pointer");
+  BP_REQUIRE(n_bits >= 1 && n_bits <= 128 && (n_bits & (n_bits - 1)) == 0, "n_bits must be a power of two <= 128");
+  BP_REQUIRE(m >= 1, "m must be >= 1");
+  uint32_t m2 = 1;
+  while (m2 < m) m2 <<= 1;
+  const uint32_t n = n_bits, nm = n * m2;
+  if (ctx->n_gens == 0) {
+    ctx->err = "generators not set (bp_generators_derive / bp_ctx_set_generators)";
+    return BP_ERR_STATE;
+  }
+  BP_REQUIRE(nm <= ctx->n_gens, "n_bits * m exceeds the generator count of the context");
+  uint32_t k = 0;
+  while ((1u << k) < nm) k++;
+  if (checked) {  // checkRanges (RangeProof/Internal.hs:164-165)
+    for (uint32_t j = 0; j < m; j++) {
+      const uint8_t* v = values + (size_t)j * 32;
+      for (uint32_t bit = n; bit < 256; bit++)
+        if ((v[bit >> 3] >> (bit & 7)) & 1) {
+          ctx->err = "ValuesNotInRange";
+          return BP_ERR_NOT_IN_RANGE;
+        }
+    }
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  const ShowStyle style = (ShowStyle)ctx->show_style;
+  hipStream_t st = ctx->stream;
+  const uint32_t ng = ctx->n_gens;
+  // aL = reversedEncodeBitMulti n vs, aR = aL - 1   (RangeProof/Internal.hs:73-88): the binary digits of each
+  // value, least significant first, zero-filled to n.  fillWithZeros never truncates, so an out-of-range value
+  // (possible only when unchecked) contributes all its digits and shifts the ones after it; the vector algebra
+  // below then zips down to nm entries while A still commits to every digit (sumExps against the infinite gs/hs).
+  const Fr4 one = fr_one(), zero = fr_zero(), minus1 = fr_neg(one);
+  std::vector<Fr4> aL, aR;
+  aL.reserve(nm);
+  for (uint32_t j = 0; j < m2; j++) {
+    uint8_t v[32] = {0};
+    if (j < m) fr_to_bytes(fr_from_bytes(values + (size_t)j * 32), v);  // Fr: canonical residue
+    uint32_t len = n;
+    for (uint32_t bit = 255; bit >= n; bit--)
+      if ((v[bit >> 3] >> (bit & 7)) & 1) {
+        len = bit + 1;
+        break;
+      }
+    for (uint32_t b = 0; b < len; b++) aL.push_back(((v[b >> 3] >> (b & 7)) & 1) ? one : zero);
+  }
+  const uint32_t n_digits = (uint32_t)aL.size();  // == nm unless some value is out of range
+  BP_REQUIRE(n_digits <= ng, "out-of-range values need more generators than the context holds");
+  aR.resize(n_digits);
+  for (uint32_t i = 0; i < n_digits; i++) aR[i] = fr_is_zero(aL[i]) ? minus1 : zero;
+  ProverWs w;
+  int rc = carve_ws(ctx, n_digits, w);
+  if (rc != BP_OK) return rc;
+  const uint8_t* d_gs = ctx->d_bases;
+  const uint8_t* d_hs = ctx->d_bases + (size_t)ng * 64;
+  const uint8_t* d_gen = ctx->d_bases + (size_t)2 * ng * 64;
+  const uint8_t* d_h = ctx->d_bases + (size_t)(2 * ng + 1) * 64;
+  uint8_t gen_h[128];
+  BP_TRY(hipMemcpyAsync(gen_h, d_gen, 128, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  std::vector<Fr4> sLv(nm), sRv(nm);
+  for (uint32_t i = 0; i < nm; i++) {
+    sLv[i] = fr_from_bytes(sL + (size_t)i * 32);
+    sRv[i] = fr_from_bytes(sR + (size_t)i * 32);
+  }
+  uint8_t* A = proof_points;
+  uint8_t* S = proof_points + 64;
+  uint8_t* T1 = proof_points + 128;
+  uint8_t* T2 = proof_points + 192;
+  // commitBitVectors: A = aBlinding*h + <aL, gs> + <aR, hs>, S likewise   (RangeProof/Internal.hs:136-147)
+  if ((rc = msm3(ctx, w, d_gs, aL, 0, d_hs, aR, 0, n_digits, d_h, fr_from_bytes(alpha), A)) != BP_OK) return rc;
+  if ((rc = msm3(ctx, w, d_gs, sLv, 0, d_hs, sRv, 0, nm, d_h, fr_from_bytes(rho), S)) != BP_OK) return rc;
+  // y, z   (Prover.hs:75-76)
+  uint8_t buf[MSG_SCRATCH], keep[MSG_SCRATCH], yb[32], zb[32], xb[32];
+  Msg my(buf, style);
+  my.r();
+  my.point(A);
+  my.point(S);
+  size_t pre = my.len;
+  memcpy(keep, buf, pre);
+  my.finish_fr(yb);
+  Msg mz(buf, style);
+  mz.raw(keep, pre);
+  mz.fr(yb);
+  mz.finish_fr(zb);
+  const Fr4 y = fr_from_bytes(yb), z = fr_from_bytes(zb);
+  // computeLRPolys / computeTPoly   (Prover.hs:133-169)
+  std::vector<Fr4> l0(nm), r0(nm), r1(nm), ypow(nm), zpow(m2 + 3);
+  zpow[0] = one;
+  for (uint32_t e = 1; e < m2 + 3; e++) zpow[e] = fr_mul(zpow[e - 1], z);
+  {
+    Fr4 yi = one, two = fr_add(one, one);
+    for (uint32_t j = 0; j < m2; j++) {
+      Fr4 two_k = one;
+      for (uint32_t b = 0; b < n; b++) {
+        uint32_t i = j * n + b;
+        ypow[i] = yi;  // powerVector y nm (y = 0 has probability 2^-256; its 0^0 = 0 quirk is not reproduced)
+        l0[i] = fr_sub(aL[i], z);
+        r0[i] = fr_add(fr_mul(yi, fr_add(aR[i], z)), fr_mul(zpow[j + 2], two_k));
+        r1[i] = fr_mul(yi, sRv[i]);
+        yi = fr_mul(yi, y);
+        two_k = fr_mul(two_k, two);
+      }
+    }
+  }
+  Fr4 t0 = zero, t1 = zero, t2 = zero;
+  for (uint32_t i = 0; i < nm; i++) {
+    t0 = fr_add(t0, fr_mul(l0[i], r0[i]));
+    t2 = fr_add(t2, fr_mul(sLv[i], r1[i]));
+    t1 = fr_add(t1, fr_add(fr_mul(sLv[i], r0[i]), fr_mul(l0[i], r1[i])));
+  }
+  // t1Commit = commit t1 t1Blinding, t2Commit likewise   (Prover.hs:84-85; Utils.hs:84-85)
+  {
+    uint8_t e0[64], e1[64], p0[128], p1[128], out[128];
+    fr_to_bytes(t1, e0);
+    fr_to_bytes(t2, e0 + 32);
+    memcpy(e1, tau1, 32);
+    memcpy(e1 + 32, tau2, 32);
+    memcpy(p0, gen_h, 64);
+    memcpy(p0 + 64, gen_h, 64);
+    memcpy(p1, gen_h + 64, 64);
+    memcpy(p1 + 64, gen_h + 64, 64);
+    if ((rc = bp_add_two_mul(ctx, e0, p0, e1, p1, 2, out)) != BP_OK) return rc;
+    memcpy(T1, out, 64);
+    memcpy(T2, out + 64, 64);
+  }
+  // x   (Prover.hs:88)
+  Msg mx(buf, style);
+  mx.raw(keep, pre);
+  mx.point(T1);
+  mx.point(T2);
+  mx.fr(yb);
+  mx.fr(zb);
+  mx.finish_fr(xb);
+  const Fr4 x = fr_from_bytes(xb), x2 = fr_sqr(x);
+  // ls, rs, t, tBlinding, mu   (Prover.hs:90-103)
+  std::vector<Fr4> ls(nm), rs(nm);
+  Fr4 t = fr_add(fr_add(t0, fr_mul(t1, x)), fr_mul(t2, x2));
+  Fr4 dotlr = zero;
+  for (uint32_t i = 0; i < nm; i++) {
+    ls[i] = fr_add(l0[i], fr_mul(x, sLv[i]));
+    rs[i] = fr_add(r0[i], fr_mul(x, r1[i]));
+    dotlr = fr_add(dotlr, fr_mul(ls[i], rs[i]));
+  }
+  if (!fr_eq(t, dotlr)) {  // the reference panics here (Prover.hs:94-95)
+    ctx->err = "Error on: t = dot l r";
+    return BP_ERR_STATE;
+  }
+  Fr4 tb = fr_add(fr_mul(fr_from_bytes(tau2), x2), fr_mul(fr_from_bytes(tau1), x));
+  for (uint32_t j = 0; j < m; j++) tb = fr_add(tb, fr_mul(zpow[j + 2], fr_from_bytes(blindings + (size_t)j * 32)));
+  Fr4 mu = fr_add(fr_from_bytes(alpha), fr_mul(fr_from_bytes(rho), x));
+  fr_to_bytes(tb, proof_scalars);
+  fr_to_bytes(mu, proof_scalars + 32);
+  fr_to_bytes(t, proof_scalars + 64);
+  // u = gen * shamirU tBlinding mu t   (Prover.hs:105-106)
+  uint8_t ub[32], u[64];
+  Msg mu_(buf, style);
+  mu_.r();
+  mu_.fr(proof_scalars);
+  mu_.fr(proof_scalars + 32);
+  mu_.fr(proof_scalars + 64);
+  mu_.finish_fr(ub);
+  if ((rc = bp_point_mul(ctx, ub, gen_h, 1, u)) != BP_OK) return rc;
+  // hs' = hs_i * recip(y^i)   (Prover.hs:107): one batched inversion on the host, one GLV kernel
+  {
+    std::vector<uint8_t> sc((size_t)nm * 32);
+    Fr4 yinv = fr_inv(y), cur = one;
+    for (uint32_t i = 0; i < nm; i++) {
+      fr_to_bytes(cur, &sc[(size_t)i * 32]);
+      cur = fr_mul(cur, yinv);
+    }
+    BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+    if ((rc = ipp_scale_points(ctx, d_hs, w.sc, nm, w.tab, w.H)) != BP_OK) return rc;
+    BP_TRY(hipMemcpyAsync(w.G, d_gs, (size_t)nm * 64, hipMemcpyDeviceToDevice, st));
+    BP_TRY(hipStreamSynchronize(st));
+  }
+  // commitmentLR = computeLRCommitment ...   (Prover.hs:108).  For the prover's own ls, rs, t this is the
+  // same group element as <ls, gs> + <rs, hs'> + t*u (expand A, S, mu in RangeProof/Internal.hs:183-198),
+  // which is one MSM.
+  uint8_t P[64];
+  {
+    uint8_t* d_u = w.small;
+    BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, st));
+    if ((rc = msm3(ctx, w, w.G, ls, 0, w.H, rs, 0, nm, d_u, t, P)) != BP_OK) return rc;
+    if (n_digits > nm) {  // digits of out-of-range values that only aCommit carries
+      uint8_t extra[64], sum[64];
+      if ((rc = msm3(ctx, w, d_gs + (size_t)nm * 64, aL, nm, d_hs + (size_t)nm * 64, aR, nm, n_digits - nm, d_u, zero,
+                     extra)) != BP_OK)
+        return rc;
+      if ((rc = bp_point_add(ctx, P, extra, 1, sum)) != BP_OK) return rc;
+      memcpy(P, sum, 64);
+    }
+  }
+  // productProof = IPP.generateProof (gs, hs', u) commitmentLR (ls, rs)   (Prover.hs:109-112)
+  std::vector<uint8_t> Lv, Rv;
+  rc = ipp_prove_core(ctx, w, nm, u, P, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
+  if (rc != BP_OK) return rc;
+  if (k) {
+    memcpy(proof_points + 256, Lv.data(), (size_t)k * 64);
+    memcpy(proof_points + 256 + (size_t)k * 64, Rv.data(), (size_t)k * 64);
+  }
+  return BP_OK;
+}
+
+}  // extern "C"

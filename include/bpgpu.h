@@ -39,6 +39,9 @@ extern "C" {
 #define BP_ERR_DEVICE (-2)  /* HIP runtime error */
 #define BP_ERR_NOMEM (-3)   /* device allocation failed */
 #define BP_ERR_STATE (-4)   /* call out of order (e.g. generators not set) */
+#define BP_ERR_NOT_IN_RANGE (-5)    /* RangeProofError ValuesNotInRange  (RangeProof/Internal.hs:40-45) */
+#define BP_ERR_BOUND_TOO_LARGE (-6) /* RangeProofError UpperBoundTooLarge */
+#define BP_ERR_N_NOT_POW2 (-7)      /* RangeProofError NNotPowerOf2 */
 
 typedef struct bp_ctx bp_ctx;
 
@@ -185,6 +188,33 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
 void bp_vjob_destroy(bp_vjob* job);
 int bp_vjob_load(bp_vjob* job, const uint8_t* scalars, const uint8_t* points);
 int bp_vjob_run(bp_vjob* job, uint8_t* verdicts);
+
+/* ---- prover path ----
+ *
+ * bp_ipp_prove      InnerProductProof.generateProof on an arbitrary base
+ *                   (Bulletproofs/InnerProductProof/Prover.hs:17-92): Gs, Hs n points, u = bH, P = commitmentLR,
+ *                   ls, rs n scalars; n = 0 or a power of two.  L_out, R_out: log2(n) points each in round
+ *                   order; l_out, r_out: 32 bytes.  Per round the L/R commitments are one bucket MSM each, the
+ *                   generator folds (Prover.hs:81-82) one GLV kernel each; x = shamirX' is hashed on the host.
+ * bp_upper_bound_bits   the validation of generateProof (MultiRangeProof/Prover.hs:25-38): n = log2(upperBound),
+ *                   BP_ERR_BOUND_TOO_LARGE if upperBound >= r, BP_ERR_N_NOT_POW2 unless upperBound = 2^n with
+ *                   n a power of two.  upper_bound: little-endian integer of `len` bytes.
+ * bp_rangeproof_prove   MultiRangeProof.generateProof (checked != 0, with checkRanges -> BP_ERR_NOT_IN_RANGE)
+ *                   or generateProofUnsafe (checked = 0) (MultiRangeProof/Prover.hs:19-123); m = 1 is
+ *                   RangeProof.generateProof (RangeProof/Prover.hs:15-32).  The MonadRandom draws become explicit
+ *                   inputs in draw order: sL, sR (n_bits*m2 scalars each, m2 = m rounded up to a power of two,
+ *                   Utils.hs:135-139), alpha = aBlinding, rho = sBlinding (Prover.hs:69-70), tau1, tau2 =
+ *                   t1Blinding, t2Blinding (:81-82).  Outputs: proof_scalars 5 x 32 B (tBlinding, mu, t, l, r),
+ *                   proof_points (4 + 2k) x 64 B (aCommit, sCommit, t1Commit, t2Commit, lCommits, rCommits).
+ */
+int bp_ipp_prove(bp_ctx* ctx, uint32_t n, const uint8_t* Gs, const uint8_t* Hs, const uint8_t* u, const uint8_t* P,
+                 const uint8_t* ls, const uint8_t* rs, uint8_t* L_out, uint8_t* R_out, uint8_t* l_out,
+                 uint8_t* r_out);
+int bp_upper_bound_bits(const uint8_t* upper_bound, size_t len, uint32_t* n_bits);
+int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t* values, const uint8_t* blindings,
+                        const uint8_t* sL, const uint8_t* sR, const uint8_t* alpha, const uint8_t* rho,
+                        const uint8_t* tau1, const uint8_t* tau2, int checked, uint8_t* proof_scalars,
+                        uint8_t* proof_points);
 
 /* ---- field arithmetic self-test hooks (used by the parity tests) ----
  * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a),

@@ -31,3 +31,16 @@ def test_version_and_argument_errors_without_gpu():
     assert lib.bp_ctx_create(None, 0) == -1  # BP_ERR_ARG: null out pointer
     assert lib.bp_last_error(None) == b"null context"
     assert lib.bp_msm(None, None, None, 0, None) == -1
+
+
+def test_upper_bound_validation_needs_no_gpu():
+    """generateProof's guards (MultiRangeProof/Prover.hs:25-38) are host arithmetic."""
+    from bulletproofs_amd import _lib
+    import bp_oracle as o
+    assert _lib.upper_bound_bits(2**64) == 64
+    assert _lib.upper_bound_bits(2**2) == 2
+    assert _lib.upper_bound_bits(o.R) == -6
+    assert _lib.upper_bound_bits(o.R - 1) == -7
+    assert _lib.upper_bound_bits(2**3) == -7
+    assert _lib.upper_bound_bits(2**0) == -7      # n = 0: logBase2M 0 = Nothing
+    assert _lib.upper_bound_bits(0) == -7
