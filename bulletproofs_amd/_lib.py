@@ -61,6 +61,9 @@ SYMBOLS = {
     "bp_ipp_prove": (_int, [_vp, ctypes.c_uint32] + [_u8p] * 10),
     "bp_upper_bound_bits": (_int, [_u8p, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "bp_rangeproof_prove": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32] + [_u8p] * 8 + [_int, _u8p, _u8p]),
+    "bp_ac_proof_points": (_int, [ctypes.c_uint32]),
+    "bp_ac_prove": (_int, [_vp] + [ctypes.c_uint32] * 3 + [_u8p] * 14),
+    "bp_ac_verify": (_int, [_vp] + [ctypes.c_uint32] * 3 + [_u8p] * 9),
 }
 
 
@@ -89,8 +92,16 @@ def load_library():
 
 
 # ---- encodings -----------------------------------------------------------------
+R_ORDER = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141  # _r
+
+
 def enc_scalar(s):
     return int(s).to_bytes(32, "little")
+
+
+def enc_fr(ss):
+    """Fr literals as Haskell reads them (`fromInteger`: -1 is r - 1)."""
+    return b"".join(enc_scalar(int(s) % R_ORDER) for s in ss)
 
 
 def dec_scalar(b):
@@ -291,6 +302,51 @@ class Engine:
         p = dec_points(pts.raw, 4 + 2 * k)
         return dict(tBlinding=s[0], mu=s[1], t=s[2], aCommit=p[0], sCommit=p[1], t1Commit=p[2], t2Commit=p[3],
                     productProof=dict(lCommits=p[4:4 + k], rCommits=p[4 + k:4 + 2 * k], l=s[3], r=s[4]))
+
+    @staticmethod
+    def _enc_circuit(circuit):
+        """dict(wL, wR, wO, commitmentWeights, cs) (ArithCircuit, ArithmeticCircuit/Internal.hs:42-58) -> dense bytes."""
+        w_l = circuit["wL"]
+        q = len(circuit["commitmentWeights"])
+        n = len(w_l[0]) if w_l else 0
+        m = len(circuit["commitmentWeights"][0]) if q else 0
+        flat = lambda rows: enc_fr([v for row in rows for v in row])
+        return n, q, m, flat(w_l), flat(circuit["wR"]), flat(circuit["wO"]), flat(circuit["commitmentWeights"]), \
+            enc_fr(circuit["cs"])
+
+    def ac_prove(self, circuit, witness, ai_blinding, ao_blinding, s_blinding, s_l, s_r, t_randoms):
+        """ArithmeticCircuit.generateProof (ArithmeticCircuit/Prover.hs:16-117) with explicit blinders;
+        returns the proof as the oracle's dict."""
+        n, q, m, w_l, w_r, w_o, w_v, _cs = self._enc_circuit(circuit)
+        asg = witness["assignment"]
+        assert len(asg["aL"]) == n
+        npts = self.lib.bp_ac_proof_points(n)
+        k = (npts - 10) // 2
+        sc = ctypes.create_string_buffer(5 * 32)
+        pts = ctypes.create_string_buffer(npts * 64)
+        self._check(self.lib.bp_ac_prove(
+            self.h, n, q, m, w_l, w_r, w_o, w_v, enc_fr(asg["aL"]), enc_fr(asg["aR"]),
+            enc_fr(asg["aO"]), enc_fr(witness["commitBlinders"]),
+            enc_fr([ai_blinding, ao_blinding, s_blinding]), enc_fr(s_l), enc_fr(s_r),
+            enc_fr(t_randoms), sc, pts), "bp_ac_prove")
+        s = dec_scalars(sc.raw, 5)
+        p = dec_points(pts.raw, npts)
+        return dict(tBlinding=s[0], mu=s[1], t=s[2], aiCommit=p[0], aoCommit=p[1], sCommit=p[2], tCommits=p[3:10],
+                    productProof=dict(lCommits=p[10:10 + k], rCommits=p[10 + k:10 + 2 * k], l=s[3], r=s[4]))
+
+    def ac_verify(self, v_commits, proof, circuit):
+        """ArithmeticCircuit.verifyProof (ArithmeticCircuit/Verifier.hs:16-71) -> bool."""
+        n, q, m, w_l, w_r, w_o, w_v, cs = self._enc_circuit(circuit)
+        assert len(v_commits) == m
+        ipp = proof["productProof"]
+        sc = enc_scalars([proof["tBlinding"], proof["mu"], proof["t"], ipp["l"], ipp["r"]])
+        pts = enc_points([proof["aiCommit"], proof["aoCommit"], proof["sCommit"]] + list(proof["tCommits"])
+                         + list(ipp["lCommits"]) + list(ipp["rCommits"]))
+        assert len(pts) == 64 * self.lib.bp_ac_proof_points(n)
+        out = ctypes.create_string_buffer(1)
+        self._check(self.lib.bp_ac_verify(self.h, n, q, m, w_l, w_r, w_o, w_v, cs, enc_points(v_commits), sc, pts,
+                                          out), "bp_ac_verify")
+        return out.raw[0] != 0
 
     def vjob(self, n_bits, m, batch, n_chunks=0, host_threads=0):
         return VJob(self, n_bits, m, batch, n_chunks, host_threads)

@@ -1,0 +1,453 @@
+// Host control of the arithmetic-circuit protocol, in C++ above the engine:
+//   ArithmeticCircuit.generateProof   (/root/reference/Bulletproofs/ArithmeticCircuit/Prover.hs:16-117)
+//   ArithmeticCircuit.verifyProof     (ArithmeticCircuit/Verifier.hs:16-71)
+//   padCircuit / padAssignment / delta / commitBitVector / shamirGxGxG / shamirGs / shamirZ
+//                                     (ArithmeticCircuit/Internal.hs:76-117)
+// Every sumExps / commitBitVector / commitmentLR is one bucket MSM on the GPU over the context's
+// device-resident gs / hs; hs' and the IPP folds are the GLV kernels of ipp.hip; the accumulator
+// walk of mkChallenges runs k_lincomb2_add once per round.  The O(Q n) weight algebra, the
+// polynomial coefficients and the Fiat-Shamir transcript stay on the host.
+// Randomness: aiBlinding, aoBlinding, sBlinding, sL, sR and the five
+// tBlindings are explicit arguments in the reference's draw order.
+#include "prover.h"
+
+using namespace bp;
+using namespace bp::host;
+
+namespace {
+
+constexpr size_t AC_MSG = 2048;  // shamirGs over 7 points is the longest transcript here
+
+// `powerVector a n` (Utils.hs:50-52), including 0^0 = 0
+std::vector<Fr4> power_vector(const Fr4& a, uint32_t n) {
+  std::vector<Fr4> v(n);
+  if (fr_is_zero(a)) {
+    for (auto& e : v) e = fr_zero();
+    return v;
+  }
+  Fr4 cur = fr_one();
+  for (uint32_t i = 0; i < n; i++) {
+    v[i] = cur;
+    cur = fr_mul(cur, a);
+  }
+  return v;
+}
+
+uint32_t pad_pow2(uint32_t n) {  // padToNearestPowerOfTwo (Utils.hs:107-121): [] stays []
+  if (n == 0) return 0;
+  uint32_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// Everything both sides derive from (circuit, y, z): ArithmeticCircuit/Prover.hs:37-42 == Verifier.hs:32-36
+struct Derived {
+  std::vector<Fr4> zs, ys, yinv, zwL, zwR, zwO;
+};
+
+// zs `vectorMatrixProduct` W for a dense q x n matrix of canonical scalars, zero-padded to n2 columns
+std::vector<Fr4> zs_times(const std::vector<Fr4>& zs, const uint8_t* W, uint32_t q, uint32_t n, uint32_t n2) {
+  std::vector<Fr4> out(n2, fr_zero());
+  for (uint32_t r = 0; r < q; r++)
+    for (uint32_t c = 0; c < n; c++) {
+      const uint8_t* e = W + ((size_t)r * n + c) * 32;
+      bool zero = true;
+      for (int b = 0; b < 32; b++)
+        if (e[b]) {
+          zero = false;
+          break;
+        }
+      if (!zero) out[c] = fr_add(out[c], fr_mul(zs[r], fr_from_bytes(e)));
+    }
+  return out;
+}
+
+Derived derive(uint32_t n, uint32_t n2, uint32_t q, const uint8_t* wL, const uint8_t* wR, const uint8_t* wO,
+               const Fr4& y, const Fr4& z) {
+  Derived d;
+  std::vector<Fr4> zp = power_vector(z, q + 1);
+  d.zs.assign(zp.begin() + 1, zp.end());  // drop 1 (powerVector z (qLen + 1))
+  d.ys = power_vector(y, n2);
+  d.yinv = power_vector(fr_inv(y), n2);
+  d.zwL = zs_times(d.zs, wL, q, n, n2);
+  d.zwR = zs_times(d.zs, wR, q, n, n2);
+  d.zwO = zs_times(d.zs, wO, q, n, n2);
+  return d;
+}
+
+void challenge_y_z(ShowStyle style, const uint8_t* AI, const uint8_t* AO, const uint8_t* S, uint8_t yb[32],
+                   uint8_t zb[32]) {
+  uint8_t buf[AC_MSG];
+  Msg my(buf, style);  // shamirGxGxG aiCommit aoCommit sCommit
+  my.r();
+  my.point(AI);
+  my.point(AO);
+  my.point(S);
+  my.finish_fr(yb);
+  Msg mz(buf, style);  // shamirZ y = oracle (show _r <> show y)
+  mz.r();
+  mz.fr(yb);
+  mz.finish_fr(zb);
+}
+
+void challenge_x(ShowStyle style, const uint8_t* T7, uint8_t xb[32]) {
+  uint8_t buf[AC_MSG];
+  Msg mx(buf, style);  // shamirGs tCommits
+  mx.r();
+  for (int i = 0; i < 7; i++) mx.point(T7 + 64 * i);
+  mx.finish_fr(xb);
+}
+
+void challenge_u(ShowStyle style, const uint8_t* three_scalars, uint8_t ub[32]) {
+  uint8_t buf[AC_MSG];
+  Msg m(buf, style);
+  m.r();
+  m.fr(three_scalars);
+  m.fr(three_scalars + 32);
+  m.fr(three_scalars + 64);
+  m.finish_fr(ub);
+}
+
+struct Gens {
+  const uint8_t *d_gs, *d_hs, *d_gen, *d_h;
+  uint8_t gen_h[128];  // host copies of gen, h
+};
+
+int get_gens(bp_ctx* ctx, Gens& g) {
+  const uint32_t ng = ctx->n_gens;
+  g.d_gs = ctx->d_bases;
+  g.d_hs = ctx->d_bases + (size_t)ng * 64;
+  g.d_gen = ctx->d_bases + (size_t)2 * ng * 64;
+  g.d_h = ctx->d_bases + (size_t)(2 * ng + 1) * 64;
+  BP_TRY(hipMemcpyAsync(g.gen_h, g.d_gen, 128, hipMemcpyDeviceToHost, ctx->stream));
+  BP_TRY(hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+// hs' = zipWith mul hs (powerVector (recip y) n) into w.H; gs into w.G   (Prover.hs:76, Verifier.hs:38)
+int load_ipp_base(bp_ctx* ctx, ProverWs& w, const Gens& g, const std::vector<Fr4>& yinv, uint32_t n2) {
+  if (n2 == 0) return BP_OK;
+  hipStream_t st = ctx->stream;
+  std::vector<uint8_t> sc((size_t)n2 * 32);
+  for (uint32_t i = 0; i < n2; i++) fr_to_bytes(yinv[i], &sc[(size_t)i * 32]);
+  BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+  int rc = ipp_scale_points(ctx, g.d_hs, w.sc, n2, w.tab, w.H);
+  if (rc != BP_OK) return rc;
+  BP_TRY(hipMemcpyAsync(w.G, g.d_gs, (size_t)n2 * 64, hipMemcpyDeviceToDevice, st));
+  BP_TRY(hipStreamSynchronize(st));
+  return BP_OK;
+}
+
+int check_dims(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, uint32_t& n2, uint32_t& k) {
+  BP_REQUIRE(n <= 8192 && q <= (1u << 20) && m <= (1u << 20), "circuit dimensions out of range");
+  if (ctx->n_gens == 0) {
+    ctx->err = "generators not set (bp_generators_derive / bp_ctx_set_generators)";
+    return BP_ERR_STATE;
+  }
+  n2 = pad_pow2(n);
+  BP_REQUIRE(n2 <= ctx->n_gens, "gate count exceeds the generator count of the context");
+  k = 0;
+  while ((2u << k) <= n2) k++;
+  return BP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bp_ac_proof_points(uint32_t n_gates) {
+  uint32_t n2 = pad_pow2(n_gates), k = 0;
+  while ((2u << k) <= n2) k++;
+  return (int)(10 + 2 * k);
+}
+
+int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* wL, const uint8_t* wR,
+                const uint8_t* wO, const uint8_t* wV, const uint8_t* a_l, const uint8_t* a_r, const uint8_t* a_o,
+                const uint8_t* commit_blinders, const uint8_t* blind3, const uint8_t* s_l, const uint8_t* s_r,
+                const uint8_t* tau5, uint8_t* proof_scalars, uint8_t* proof_points) {
+  if (!ctx) return BP_ERR_ARG;
+  uint32_t n2, k;
+  int rc = check_dims(ctx, n, q, m, n2, k);
+  if (rc != BP_OK) return rc;
+  BP_REQUIRE(blind3 && tau5 && proof_scalars && proof_points, "null pointer");
+  BP_REQUIRE(n == 0 || (a_l && a_r && a_o && s_l && s_r), "null pointer");
+  BP_REQUIRE(q == 0 || n == 0 || (wL && wR && wO), "null pointer");
+  BP_REQUIRE(q == 0 || m == 0 || (wV && commit_blinders), "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  const ShowStyle style = (ShowStyle)ctx->show_style;
+  ProverWs w;
+  if ((rc = carve_ws(ctx, n2 ? n2 : 1, w)) != BP_OK) return rc;
+  Gens g;
+  if ((rc = get_gens(ctx, g)) != BP_OK) return rc;
+  const Fr4 zero = fr_zero();
+
+  // padAssignment (Internal.hs:91-97); sL, sR already have the padded length (chooseBlindingVectors n, :32)
+  std::vector<Fr4> aL(n2, zero), aR(n2, zero), aO(n2, zero), sL(n2), sR(n2);
+  for (uint32_t i = 0; i < n; i++) {
+    aL[i] = fr_from_bytes(a_l + (size_t)i * 32);
+    aR[i] = fr_from_bytes(a_r + (size_t)i * 32);
+    aO[i] = fr_from_bytes(a_o + (size_t)i * 32);
+  }
+  for (uint32_t i = 0; i < n2; i++) {
+    sL[i] = fr_from_bytes(s_l + (size_t)i * 32);
+    sR[i] = fr_from_bytes(s_r + (size_t)i * 32);
+  }
+  const Fr4 aiB = fr_from_bytes(blind3), aoB = fr_from_bytes(blind3 + 32), sB = fr_from_bytes(blind3 + 64);
+  uint8_t* AI = proof_points;
+  uint8_t* AO = proof_points + 64;
+  uint8_t* S = proof_points + 128;
+  uint8_t* T = proof_points + 192;  // 7 points
+  // commitBitVector (Internal.hs:102-107): aiCommit, aoCommit (vR = []), sCommit   (Prover.hs:29-33)
+  if ((rc = msm3(ctx, w, g.d_gs, aL, 0, g.d_hs, aR, 0, n2, g.d_h, aiB, AI)) != BP_OK) return rc;
+  {
+    MsmSeg segs[2] = {{g.d_gs, n2, true}, {g.d_h, 1, true}};
+    std::vector<Fr4> sc(aO);
+    sc.push_back(aoB);
+    if ((rc = msm_gather(ctx, w, segs, 2, sc, AO)) != BP_OK) return rc;
+  }
+  if ((rc = msm3(ctx, w, g.d_gs, sL, 0, g.d_hs, sR, 0, n2, g.d_h, sB, S)) != BP_OK) return rc;
+
+  uint8_t yb[32], zb[32], xb[32];
+  challenge_y_z(style, AI, AO, S, yb, zb);
+  const Fr4 y = fr_from_bytes(yb), z = fr_from_bytes(zb);
+  Derived d = derive(n, n2, q, wL, wR, wO, y, z);
+
+  // computePolynomials (Prover.hs:104-117): l0 = 0, l1 = aL + y^-n o zwR, l2 = aO, l3 = sL;
+  // r0 = zwO - y^n, r1 = y^n o aR + zwL, r2 = 0, r3 = y^n o sR.  tPoly = multiplyPoly (Internal.hs:130-139).
+  std::vector<Fr4> l1(n2), r0(n2), r1(n2), r3(n2);
+  for (uint32_t i = 0; i < n2; i++) {
+    l1[i] = fr_add(aL[i], fr_mul(d.yinv[i], d.zwR[i]));
+    r0[i] = fr_sub(d.zwO[i], d.ys[i]);
+    r1[i] = fr_add(fr_mul(d.ys[i], aR[i]), d.zwL[i]);
+    r3[i] = fr_mul(d.ys[i], sR[i]);
+  }
+  Fr4 tc[7] = {zero, zero, zero, zero, zero, zero, zero};
+  for (uint32_t i = 0; i < n2; i++) {
+    tc[1] = fr_add(tc[1], fr_mul(l1[i], r0[i]));
+    tc[2] = fr_add(tc[2], fr_add(fr_mul(l1[i], r1[i]), fr_mul(aO[i], r0[i])));
+    tc[3] = fr_add(tc[3], fr_add(fr_mul(aO[i], r1[i]), fr_mul(sL[i], r0[i])));
+    tc[4] = fr_add(tc[4], fr_add(fr_mul(l1[i], r3[i]), fr_mul(sL[i], r1[i])));
+    tc[5] = fr_add(tc[5], fr_mul(aO[i], r3[i]));
+    tc[6] = fr_add(tc[6], fr_mul(sL[i], r3[i]));
+  }
+  // tBlindings = insertAt 2 0 (0 : five randoms); tCommits = zipWith commit tPoly tBlindings   (Prover.hs:57-58)
+  Fr4 tau[7] = {zero, fr_from_bytes(tau5), zero, fr_from_bytes(tau5 + 32), fr_from_bytes(tau5 + 64),
+                fr_from_bytes(tau5 + 96), fr_from_bytes(tau5 + 128)};
+  {
+    uint8_t e0[7 * 32], e1[7 * 32], p0[7 * 64], p1[7 * 64];
+    for (int i = 0; i < 7; i++) {
+      fr_to_bytes(tc[i], e0 + 32 * i);
+      fr_to_bytes(tau[i], e1 + 32 * i);
+      memcpy(p0 + 64 * i, g.gen_h, 64);
+      memcpy(p1 + 64 * i, g.gen_h + 64, 64);
+    }
+    if ((rc = bp_add_two_mul(ctx, e0, p0, e1, p1, 7, T)) != BP_OK) return rc;
+  }
+  challenge_x(style, T, xb);
+  const Fr4 x = fr_from_bytes(xb), x2 = fr_sqr(x), x3 = fr_mul(x2, x);
+  // ls = evaluatePolynomial n lPoly x, rs likewise, t = ls . rs   (Prover.hs:63-65)
+  std::vector<Fr4> ls(n2), rs(n2);
+  Fr4 t = zero;
+  for (uint32_t i = 0; i < n2; i++) {
+    ls[i] = fr_add(fr_add(fr_mul(x, l1[i]), fr_mul(x2, aO[i])), fr_mul(x3, sL[i]));
+    rs[i] = fr_add(fr_add(r0[i], fr_mul(x, r1[i])), fr_mul(x3, r3[i]));
+    t = fr_add(t, fr_mul(ls[i], rs[i]));
+  }
+  // tBlinding = sum tau_i x^i + x^2 * (zs . (commitBlinders `vectorMatrixProductT` commitmentWeights))   (:67-70)
+  Fr4 zGamma = zero;
+  for (uint32_t r = 0; r < q; r++) {
+    Fr4 row = zero;
+    for (uint32_t j = 0; j < m; j++)
+      row = fr_add(row, fr_mul(fr_from_bytes(commit_blinders + (size_t)j * 32),
+                               fr_from_bytes(wV + ((size_t)r * m + j) * 32)));
+    zGamma = fr_add(zGamma, fr_mul(d.zs[r], row));
+  }
+  Fr4 tB = fr_mul(x2, zGamma), xp = fr_one();
+  for (int i = 0; i < 7; i++) {
+    tB = fr_add(tB, fr_mul(tau[i], xp));
+    xp = fr_mul(xp, x);
+  }
+  Fr4 mu = fr_add(fr_add(fr_mul(aiB, x), fr_mul(aoB, x2)), fr_mul(sB, x3));  // (:72)
+  fr_to_bytes(tB, proof_scalars);
+  fr_to_bytes(mu, proof_scalars + 32);
+  fr_to_bytes(t, proof_scalars + 64);
+  // u = gen * shamirU tBlinding mu t   (:74-75)
+  uint8_t ub[32], u[64];
+  challenge_u(style, proof_scalars, ub);
+  if ((rc = bp_point_mul(ctx, ub, g.gen_h, 1, u)) != BP_OK) return rc;
+  if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
+  // commitmentLR (:77-85).  Expanding aiCommit, aoCommit, sCommit and mu, the same group element is
+  // <ls, gs> + <rs, hs'> + t*u for the prover's own ls, rs (an identity in the exponents, no
+  // circuit constraint needed), which is one MSM over the IPP base.
+  uint8_t P[64];
+  {
+    uint8_t* d_u = w.small;
+    BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = msm3(ctx, w, w.G, ls, 0, w.H, rs, 0, n2, d_u, t, P)) != BP_OK) return rc;
+  }
+  std::vector<uint8_t> Lv, Rv;
+  rc = ipp_prove_core(ctx, w, n2, u, P, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
+  if (rc != BP_OK) return rc;
+  if (k) {
+    memcpy(proof_points + 640, Lv.data(), (size_t)k * 64);
+    memcpy(proof_points + 640 + (size_t)k * 64, Rv.data(), (size_t)k * 64);
+  }
+  return BP_OK;
+}
+
+int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* wL, const uint8_t* wR,
+                 const uint8_t* wO, const uint8_t* wV, const uint8_t* cs, const uint8_t* v_commits,
+                 const uint8_t* proof_scalars, const uint8_t* proof_points, uint8_t* verdict) {
+  if (!ctx) return BP_ERR_ARG;
+  uint32_t n2, k;
+  int rc = check_dims(ctx, n, q, m, n2, k);
+  if (rc != BP_OK) return rc;
+  BP_REQUIRE(proof_scalars && proof_points && verdict, "null pointer");
+  BP_REQUIRE(q == 0 || ((n == 0 || (wL && wR && wO)) && cs), "null pointer");
+  BP_REQUIRE(m == 0 || (v_commits && (q == 0 || wV)), "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  const ShowStyle style = (ShowStyle)ctx->show_style;
+  hipStream_t st = ctx->stream;
+  ProverWs w;
+  if ((rc = carve_ws(ctx, n2 ? n2 : 1, w, m)) != BP_OK) return rc;
+  Gens g;
+  if ((rc = get_gens(ctx, g)) != BP_OK) return rc;
+  const Fr4 zero = fr_zero();
+  const uint8_t* AI = proof_points;
+  const uint8_t* AO = proof_points + 64;
+  const uint8_t* S = proof_points + 128;
+  const uint8_t* T = proof_points + 192;
+  const uint8_t* Lp = proof_points + 640;
+  const uint8_t* Rp = Lp + (size_t)k * 64;
+  const Fr4 tB = fr_from_bytes(proof_scalars), mu = fr_from_bytes(proof_scalars + 32),
+            t = fr_from_bytes(proof_scalars + 64), l = fr_from_bytes(proof_scalars + 96),
+            r = fr_from_bytes(proof_scalars + 128);
+
+  // x, y, z   (Verifier.hs:28-30)
+  uint8_t yb[32], zb[32], xb[32];
+  challenge_x(style, T, xb);
+  challenge_y_z(style, AI, AO, S, yb, zb);
+  const Fr4 x = fr_from_bytes(xb), y = fr_from_bytes(yb), z = fr_from_bytes(zb);
+  const Fr4 x2 = fr_sqr(x), x3 = fr_mul(x2, x);
+  Derived d = derive(n, n2, q, wL, wR, wO, y, z);
+  // u = gen * shamirU tBlinding mu t   (:40-41); the proof's scalars are hashed as canonical residues
+  uint8_t canon3[96], ub[32], u[64];
+  fr_to_bytes(tB, canon3);
+  fr_to_bytes(mu, canon3 + 32);
+  fr_to_bytes(t, canon3 + 64);
+  challenge_u(style, canon3, ub);
+  if ((rc = bp_point_mul(ctx, ub, g.gen_h, 1, u)) != BP_OK) return rc;
+
+  // verifyTPoly (:43-54): commit t tBlinding == gen*gExp + sumExps xs tCommits + sumExps vExp vCommits,
+  // evaluated as one multiexp of the difference, which is O exactly when both sides are equal.
+  bool t_ok;
+  {
+    Fr4 kdelta = zero, cQ = zero;  // delta n y zwL zwR (Internal.hs:99-100); cQ = zs . cs
+    for (uint32_t i = 0; i < n2; i++) kdelta = fr_add(kdelta, fr_mul(fr_mul(d.yinv[i], d.zwR[i]), d.zwL[i]));
+    for (uint32_t rr = 0; rr < q; rr++) cQ = fr_add(cQ, fr_mul(d.zs[rr], fr_from_bytes(cs + (size_t)rr * 32)));
+    Fr4 gExp = fr_mul(x2, fr_add(kdelta, cQ));
+    std::vector<Fr4> sc;
+    sc.push_back(fr_sub(t, gExp));
+    sc.push_back(tB);
+    Fr4 xp = x3;  // xs = 0 : x : 0 : x^3 .. x^6
+    Fr4 xs[7] = {zero, x, zero, zero, zero, zero, zero};
+    for (int i = 3; i < 7; i++) {
+      xs[i] = xp;
+      xp = fr_mul(xp, x);
+    }
+    for (int i = 0; i < 7; i++) sc.push_back(fr_neg(xs[i]));
+    for (uint32_t j = 0; j < m; j++) {  // vExp = x^2 * (zs `vectorMatrixProduct` commitmentWeights)
+      Fr4 col = zero;
+      for (uint32_t rr = 0; rr < q; rr++)
+        col = fr_add(col, fr_mul(d.zs[rr], fr_from_bytes(wV + ((size_t)rr * m + j) * 32)));
+      sc.push_back(fr_neg(fr_mul(x2, col)));
+    }
+    MsmSeg segs[3] = {{g.gen_h, 2, false}, {T, 7, false}, {v_commits, m, false}};
+    uint8_t diff[64];
+    if ((rc = msm_gather(ctx, w, segs, 3, sc, diff)) != BP_OK) return rc;
+    t_ok = true;
+    for (int i = 0; i < 64; i++) t_ok &= diff[i] == 0;
+  }
+
+  // verifyLRCommitment (:56-71)
+  if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
+  uint8_t acc[64];
+  {
+    // commitmentLR = x*AI + x^2*AO + x^3*S + sumExps gExp gs + sumExps hExp hs' - mu*h + t*u
+    std::vector<Fr4> sc(2 * (size_t)n2);
+    for (uint32_t i = 0; i < n2; i++) {
+      sc[i] = fr_mul(x, fr_mul(d.yinv[i], d.zwR[i]));
+      sc[n2 + i] = fr_sub(fr_add(fr_mul(x, d.zwL[i]), d.zwO[i]), d.ys[i]);
+    }
+    sc.push_back(x);
+    sc.push_back(x2);
+    sc.push_back(x3);
+    sc.push_back(fr_neg(mu));
+    sc.push_back(t);
+    uint8_t five[5 * 64];
+    memcpy(five, AI, 64);
+    memcpy(five + 64, AO, 64);
+    memcpy(five + 128, S, 64);
+    memcpy(five + 192, g.gen_h + 64, 64);
+    memcpy(five + 256, u, 64);
+    MsmSeg segs[3] = {{w.G, n2, true}, {w.H, n2, true}, {five, 5, false}};
+    if ((rc = msm_gather(ctx, w, segs, 3, sc, acc)) != BP_OK) return rc;
+  }
+  // IPP.verifyProof n (gs, hs', u) commitmentLR productProof   (InnerProductProof/Verifier.hs:18-38)
+  // mkChallenges (:40-53): x_j = shamirX' acc L_j R_j; acc <- x_j^2 L_j + x_j^-2 R_j + acc
+  std::vector<Fr4> chal(k);  // round order; the reference's list is this reversed
+  {
+    uint8_t* d_acc = w.small + 64;
+    uint8_t* d_L = w.small + 128;
+    uint8_t* d_R = w.small + 192;
+    uint8_t* d_new = w.small + 256;
+    BP_TRY(hipMemcpyAsync(d_acc, acc, 64, hipMemcpyHostToDevice, st));
+    for (uint32_t j = 0; j < k; j++) {
+      const uint8_t* Lj = Lp + (size_t)j * 64;
+      const uint8_t* Rj = Rp + (size_t)j * 64;
+      uint8_t buf[AC_MSG], xjb[32], x2b[32], xi2b[32];
+      Msg mm(buf, style);
+      mm.r();
+      mm.point(Lj);
+      mm.point(Rj);
+      mm.point(acc);
+      mm.finish_fr(xjb);
+      chal[j] = fr_from_bytes(xjb);
+      fr_to_bytes(fr_sqr(chal[j]), x2b);
+      fr_to_bytes(fr_sqr(fr_inv(chal[j])), xi2b);
+      BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
+      BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
+      if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
+      BP_TRY(hipMemcpyAsync(acc, d_new, 64, hipMemcpyDeviceToHost, st));
+      BP_TRY(hipMemcpyAsync(d_acc, d_new, 64, hipMemcpyDeviceToDevice, st));
+      BP_TRY(hipStreamSynchronize(st));
+    }
+  }
+  // mkOtherExponents (:55-73): s_0 = (prod x)^-1, s_{i + 2^j} = s_i * c_j^2 with c_0 the LAST round's challenge
+  bool lr_ok;
+  {
+    std::vector<Fr4> s(n2 ? n2 : 1);
+    Fr4 prod = fr_one();
+    for (uint32_t j = 0; j < k; j++) prod = fr_mul(prod, chal[j]);
+    s[0] = fr_inv(prod);
+    for (uint32_t i1 = 1; i1 < n2; i1++) {
+      uint32_t j = 31 - __builtin_clz(i1);
+      s[i1] = fr_mul(s[i1 - (1u << j)], fr_sqr(chal[k - 1 - j]));
+    }
+    // cProof = l*<s, gs> + r*<reverse s, hs'> + (l*r)*u   (:27-36)
+    std::vector<Fr4> sc(2 * (size_t)n2 + 1);
+    for (uint32_t i = 0; i < n2; i++) {
+      sc[i] = fr_mul(l, s[i]);
+      sc[n2 + i] = fr_mul(r, s[n2 - 1 - i]);
+    }
+    sc[2 * (size_t)n2] = fr_mul(l, r);
+    MsmSeg segs[3] = {{w.G, n2, true}, {w.H, n2, true}, {u, 1, false}};
+    uint8_t cproof[64];
+    if ((rc = msm_gather(ctx, w, segs, 3, sc, cproof)) != BP_OK) return rc;
+    lr_ok = memcmp(cproof, acc, 64) == 0;
+  }
+  *verdict = (lr_ok && t_ok) ? 1 : 0;
+  return BP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Shared pieces of the host-side prover/verifier control code (prover_host.hip, circuit_host.hip):
+// the device workspace, gathered MSMs over generator slices, and the IPP recursion.
+#pragma once
+#include <vector>
+
+#include "engine.h"
+#include "host_fr.h"
+#include "transcript.h"
+
+namespace bp {
+
+struct ProverWs {
+  uint8_t *G, *H;    // current generator vectors (affine), n points each
+  uint8_t *G2, *H2;  // fold outputs (ping-pong)
+  uint8_t* pts;      // gathered MSM points, up to 2n + 16
+  uint8_t* sc;       // MSM scalars, up to 2n + 16
+  uint8_t* small;    // 16 single points: u, P, L, R, ...; slot 15 = MSM output
+  xyzz* tab;         // 15 * n joint-table scratch
+};
+
+// carve the workspace for vectors of n points out of ctx->pws (grown on demand); `extra` more gathered terms
+int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra = 0);
+
+// One slice of a gathered MSM: `count` points at `pts` (device memory if on_device, else host memory).
+struct MsmSeg {
+  const uint8_t* pts;
+  size_t count;
+  bool on_device;
+};
+// sum_i scalars[i] * P_i over the concatenated segments -> affine result in host memory (synchronous).
+int msm_gather(bp_ctx* ctx, ProverWs& w, const MsmSeg* segs, int n_segs, const std::vector<host::Fr4>& scalars,
+               uint8_t out[64]);
+
+// MSM over [dA (cnt), dB (cnt), single] with scalars [sa[a0..], sb[b0..], s1]
+int msm3(bp_ctx* ctx, ProverWs& w, const uint8_t* dA, const std::vector<host::Fr4>& sa, size_t a0, const uint8_t* dB,
+         const std::vector<host::Fr4>& sb, size_t b0, size_t cnt, const uint8_t* d_single, const host::Fr4& s1,
+         uint8_t out[64]);
+
+// The recursion of generateProof' (InnerProductProof/Prover.hs:28-92) on device-resident w.G, w.H.
+int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], const uint8_t P0[64],
+                   std::vector<host::Fr4>& ls, std::vector<host::Fr4>& rs, host::ShowStyle style,
+                   std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs, uint8_t l_out[32], uint8_t r_out[32]);
+
+}  // namespace bp

@@ -8,35 +8,22 @@
 // algebra, bit decomposition, validation and the Fiat-Shamir transcript stay on the host.
 // Randomness: the reference draws sL, sR, aBlinding, sBlinding, t1Blinding,
 // t2Blinding from MonadRandom in that order; here they are explicit arguments.
-#include <vector>
-
-#include "engine.h"
-#include "host_fr.h"
-#include "transcript.h"
+#include "prover.h"
 
 using namespace bp;
 using namespace bp::host;
 
-namespace {
+namespace bp {
 
-struct ProverWs {
-  uint8_t *G, *H;        // current generator vectors (affine), n points each
-  uint8_t *G2, *H2;      // fold outputs (ping-pong)
-  uint8_t *pts;          // gathered MSM points, up to 2n + 1
-  uint8_t *sc;           // MSM scalars, up to 2n + 1
-  uint8_t *small;        // a few single points: u, P, L, R, out
-  xyzz* tab;             // 15 * n joint-table scratch
-};
-
-int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w) {
+int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra) {
   auto carve = [&](void* base) {
     Carver c(base);
     w.G = c.take<uint8_t>((size_t)n * 64);
     w.H = c.take<uint8_t>((size_t)n * 64);
     w.G2 = c.take<uint8_t>((size_t)n * 64);
     w.H2 = c.take<uint8_t>((size_t)n * 64);
-    w.pts = c.take<uint8_t>((size_t)(2 * n + 2) * 64);
-    w.sc = c.take<uint8_t>((size_t)(2 * n + 2) * 32);
+    w.pts = c.take<uint8_t>((size_t)(2 * n + 16 + extra) * 64);
+    w.sc = c.take<uint8_t>((size_t)(2 * n + 16 + extra) * 32);
     w.small = c.take<uint8_t>(16 * 64);
     w.tab = c.take<xyzz>((size_t)15 * (n ? n : 1));
     return c.off;
@@ -47,6 +34,32 @@ int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w) {
     return BP_ERR_NOMEM;
   }
   carve(ctx->pws.p);
+  return BP_OK;
+}
+
+int msm_gather(bp_ctx* ctx, ProverWs& w, const MsmSeg* segs, int n_segs, const std::vector<Fr4>& scalars,
+               uint8_t out[64]) {
+  hipStream_t st = ctx->stream;
+  size_t total = 0;
+  for (int i = 0; i < n_segs; i++) {
+    if (segs[i].count)
+      BP_TRY(hipMemcpyAsync(w.pts + total * 64, segs[i].pts, segs[i].count * 64,
+                            segs[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    total += segs[i].count;
+  }
+  BP_REQUIRE(total == scalars.size(), "msm_gather: scalar count does not match the segments");
+  uint8_t* d_out = w.small + 15 * 64;
+  if (total == 0) {
+    memset(out, 0, 64);
+    return BP_OK;
+  }
+  std::vector<uint8_t> sc(total * 32);
+  for (size_t i = 0; i < total; i++) fr_to_bytes(scalars[i], &sc[i * 32]);
+  BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+  int rc = msm_run(ctx, w.sc, w.pts, total, 0, d_out, nullptr);
+  if (rc != BP_OK) return rc;
+  BP_TRY(hipMemcpyAsync(out, d_out, 64, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));  // `sc` and host segments are temporaries
   return BP_OK;
 }
 
@@ -148,7 +161,7 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
   return BP_OK;
 }
 
-}  // namespace
+}  // namespace bp
 
 extern "C" {
 

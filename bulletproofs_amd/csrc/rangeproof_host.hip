@@ -364,7 +364,8 @@ int bp_transcript(int style, int which, const uint8_t* pts, const uint8_t* scs, 
                   uint8_t* out) {
   if (!out || style < 0 || style > 1) return BP_ERR_ARG;
   ShowStyle st = (ShowStyle)style;
-  std::vector<uint8_t> big(raw_len + MSG_SCRATCH);
+  if (which == 9 && raw_len > 4096) return BP_ERR_ARG;
+  std::vector<uint8_t> big((which == 9 ? raw_len * 170 : raw_len) + MSG_SCRATCH);
   Msg m(big.data(), st);
   switch (which) {
     case 0: m.r(); m.point(pts); m.point(pts + 64); break;
@@ -374,6 +375,9 @@ int bp_transcript(int style, int which, const uint8_t* pts, const uint8_t* scs, 
     case 4: m.r(); m.fr(scs); m.fr(scs + 32); m.fr(scs + 64); break;
     case 5: m.raw(raw, raw_len); break;
     case 6: m.raw(raw, raw_len); oracle(m.buf, m.len, MOD_P, out); return BP_OK;
+    case 7: m.r(); for (int i = 0; i < 3; i++) m.point(pts + 64 * i); break;
+    case 8: m.r(); m.fr(scs); break;
+    case 9: m.r(); for (size_t i = 0; i < raw_len; i++) m.point(pts + 64 * i); break;
     default: return BP_ERR_ARG;
   }
   m.finish_fr(out);

@@ -163,7 +163,10 @@ int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts);
  * bp_transcript     the reference's hash-to-scalar functions, for parity tests:
  *                   which = 0 shamirY(A,S)  1 shamirZ(A,S,y)  2 shamirX(A,S,T1,T2,y,z)
  *                   3 shamirX'(acc,L,R) [pts = acc,L,R]  4 shamirU(tBlinding,mu,t)
- *                   5 oracle(raw) into Fr  6 oracle(raw) into Fq.  out: 32 bytes.
+ *                   5 oracle(raw) into Fr  6 oracle(raw) into Fq
+ *                   7 shamirGxGxG(p1,p2,p3)  8 the circuit protocol's shamirZ(z) [scs = z]
+ *                   9 shamirGs(ps) over raw_len points (raw unused)
+ *                   (ArithmeticCircuit/Internal.hs:109-117).  out: 32 bytes.
  *
  * bp_rangeproof_verify_batch   verdicts[i] = MultiRangeProof.verifyProof 2^n_bits vCommits_i proof_i
  *                   (MultiRangeProof/Verifier.hs:19-39; m = 1 is RangeProof.verifyProof,
@@ -215,6 +218,32 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
                         const uint8_t* sL, const uint8_t* sR, const uint8_t* alpha, const uint8_t* rho,
                         const uint8_t* tau1, const uint8_t* tau2, int checked, uint8_t* proof_scalars,
                         uint8_t* proof_points);
+
+/* ---- arithmetic circuits (host control in C++ over the same engine) ----
+ * A circuit (ArithCircuit, ArithmeticCircuit/Internal.hs:42-58) is passed as dense row-major matrices of
+ * canonical scalars: wL, wR, wO are q x n (n = multiplication gates, unpadded), wV = commitmentWeights is
+ * q x m, cs has q entries.  padCircuit / padAssignment (Internal.hs:76-97) happen inside: n2 = n rounded up
+ * to a power of two (0 stays 0), k = log2(n2).
+ *
+ * bp_ac_proof_points   number of points in a proof for n gates: 10 + 2k.
+ * bp_ac_prove       ArithmeticCircuit.generateProof (ArithmeticCircuit/Prover.hs:16-117).  a_l, a_r, a_o: n
+ *                   scalars (Assignment); commit_blinders: m scalars (ArithWitness.commitBlinders; the witness's
+ *                   `commitments` are not read by the prover).  The MonadRandom draws are explicit inputs in
+ *                   draw order: blind3 = aiBlinding, aoBlinding, sBlinding (:25-27); s_l, s_r: n2 scalars each
+ *                   (chooseBlindingVectors n, :32); tau5: the five tBlindings of :57 (they land at degrees
+ *                   1, 3, 4, 5, 6).  Outputs: proof_scalars 5 x 32 B (tBlinding, mu, t, l, r); proof_points
+ *                   (10 + 2k) x 64 B (aiCommit, aoCommit, sCommit, tCommits[0..6], lCommits, rCommits).
+ * bp_ac_verify      ArithmeticCircuit.verifyProof (ArithmeticCircuit/Verifier.hs:16-71): *verdict = 1/0.
+ *                   v_commits: m points.  Needs generators for n2 (bp_generators_derive).
+ */
+int bp_ac_proof_points(uint32_t n_gates);
+int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* wL, const uint8_t* wR,
+                const uint8_t* wO, const uint8_t* wV, const uint8_t* a_l, const uint8_t* a_r, const uint8_t* a_o,
+                const uint8_t* commit_blinders, const uint8_t* blind3, const uint8_t* s_l, const uint8_t* s_r,
+                const uint8_t* tau5, uint8_t* proof_scalars, uint8_t* proof_points);
+int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* wL, const uint8_t* wR,
+                 const uint8_t* wO, const uint8_t* wV, const uint8_t* cs, const uint8_t* v_commits,
+                 const uint8_t* proof_scalars, const uint8_t* proof_points, uint8_t* verdict);
 
 /* ---- field arithmetic self-test hooks (used by the parity tests) ----
  * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a),

@@ -661,3 +661,196 @@ def draw_blinders(rng, nm):
     s_r = [rng.randint(1, 2**nm - 1) % R for _ in range(nm)]
     rest = [rng.randint(1, R - 1) for _ in range(4)]
     return (s_l, s_r, *rest)
+
+
+# --------------------------------------------------------------------------
+# Arithmetic circuits (ArithmeticCircuit/{Internal,Prover,Verifier}.hs) -- a-17
+# --------------------------------------------------------------------------
+def pad_to_nearest_power_of_two(xs):
+    """Utils.hs:107-121: [] stays []; otherwise zero-extend to 2^log2Ceil(length)."""
+    if not xs:
+        return []
+    return list(xs) + [0] * (2**log2_ceil(len(xs)) - len(xs))
+
+
+def pad_circuit(circuit):
+    """ArithmeticCircuit/Internal.hs:76-87.  circuit = dict(wL, wR, wO, commitmentWeights, cs)."""
+    return dict(circuit, wL=[pad_to_nearest_power_of_two(r) for r in circuit["wL"]],
+                wR=[pad_to_nearest_power_of_two(r) for r in circuit["wR"]],
+                wO=[pad_to_nearest_power_of_two(r) for r in circuit["wO"]])
+
+
+def pad_assignment(asg):
+    """ArithmeticCircuit/Internal.hs:91-97.  asg = dict(aL, aR, aO)."""
+    return dict(aL=pad_to_nearest_power_of_two(asg["aL"]), aR=pad_to_nearest_power_of_two(asg["aR"]),
+                aO=pad_to_nearest_power_of_two(asg["aO"]))
+
+
+def ac_delta(n, y, zw_l, zw_r):
+    """ArithmeticCircuit/Internal.hs:99-100."""
+    return dot(hadamard(power_vector(pow(y, -1, R), n), zw_r), zw_l)
+
+
+def commit_bit_vector(v_blinding, v_l, v_r):
+    """ArithmeticCircuit/Internal.hs:102-107 (vLG <> vRH <> vBlindingH)."""
+    n = max(len(v_l), len(v_r))
+    return point_add(point_add(sum_exps(v_l, gs(n)), sum_exps(v_r, hs(n))), point_mul(h(), v_blinding))
+
+
+def shamir_gxgxg(p1, p2, p3):
+    """ArithmeticCircuit/Internal.hs:109-111."""
+    return oracle(SHOW_R + show_point(p1) + show_point(p2) + show_point(p3))
+
+
+def shamir_gs(ps):
+    """ArithmeticCircuit/Internal.hs:113-114."""
+    return oracle(SHOW_R + b"".join(show_point(p) for p in ps))
+
+
+def ac_shamir_z(z):
+    """ArithmeticCircuit/Internal.hs:116-117 (the prover/verifier hide Utils.shamirZ)."""
+    return oracle(SHOW_R + show_fr(z))
+
+
+def evaluate_polynomial(n, poly, x):
+    """ArithmeticCircuit/Internal.hs:123-128."""
+    acc = [0] * n
+    for idx, e in enumerate(poly):
+        acc = vadd(acc, [pow(x, idx, R) * v % R for v in e])
+    return acc
+
+
+def multiply_poly(l, r):
+    """ArithmeticCircuit/Internal.hs:130-139: coefficients by ascending degree i + j."""
+    acc = {}
+    for i, li in enumerate(l):
+        for j, rj in enumerate(r):
+            acc[i + j] = (acc.get(i + j, 0) + dot(li, rj)) % R
+    return [acc[k] for k in sorted(acc)]
+
+
+def vector_matrix_product(v, m):
+    """ArithmeticCircuit/Internal.hs:146-148: v * M, one entry per column (transpose truncates to
+    the shortest row only when rows are ragged; the circuits here are rectangular)."""
+    cols = max((len(row) for row in m), default=0)
+    out = []
+    for c in range(cols):
+        col = [row[c] for row in m if c < len(row)]
+        out.append(sum(a * b for a, b in zip(v, col)) % R)
+    return out
+
+
+def vector_matrix_product_t(v, m):
+    """ArithmeticCircuit/Internal.hs:150-152: one entry per row."""
+    return [sum(a * b for a, b in zip(v, row)) % R for row in m]
+
+
+def insert_at(z, y, xs):
+    """ArithmeticCircuit/Internal.hs:165-168."""
+    return list(xs[:z]) + [y] + list(xs[z:])
+
+
+def ac_lr_commitment(n, proof_pts, x, y, zw_l, zw_r, zw_o, mu, t, u, hsp):
+    """`commitmentLR` (ArithmeticCircuit/Prover.hs:77-85 == Verifier.hs:63-71)."""
+    ai, ao, s = proof_pts
+    ys = power_vector(y, n)
+    g_exp = [x * v % R for v in hadamard(power_vector(pow(y, -1, R), n), zw_r)]
+    h_exp = vsub(vadd([x * v % R for v in zw_l], zw_o), ys)
+    acc = point_mul(ai, x)
+    acc = point_add(acc, point_mul(ao, x * x % R))
+    acc = point_add(acc, point_mul(s, pow(x, 3, R)))
+    acc = point_add(acc, sum_exps(g_exp, gs(n)))
+    acc = point_add(acc, sum_exps(h_exp, hsp))
+    acc = point_add(acc, point_neg(point_mul(h(), mu)))
+    acc = point_add(acc, point_mul(u, t))
+    return acc
+
+
+def ac_generate_proof(circuit, witness, ai_blinding, ao_blinding, s_blinding, s_l, s_r, t_randoms, trace=None):
+    """`generateProof` (ArithmeticCircuit/Prover.hs:16-117).
+
+    witness = dict(assignment=dict(aL, aR, aO), commitments, commitBlinders).
+    U3 draw order of the reference: aiBlinding, aoBlinding, sBlinding (:25-27), sL, sR (:32),
+    then five tBlindings (:57) which land at indices 1, 3, 4, 5, 6 (0 at indices 0 and 2)."""
+    c = pad_circuit(circuit)
+    w_l, w_r, w_o = c["wL"], c["wR"], c["wO"]
+    asg = pad_assignment(witness["assignment"])
+    a_l, a_r, a_o = ([v % R for v in asg[k]] for k in ("aL", "aR", "aO"))
+    q_len = len(c["commitmentWeights"])
+    n = len(a_l)
+    ai_commit = commit_bit_vector(ai_blinding, a_l, a_r)
+    ao_commit = commit_bit_vector(ao_blinding, a_o, [])
+    s_l = [v % R for v in s_l]
+    s_r = [v % R for v in s_r]
+    s_commit = commit_bit_vector(s_blinding, s_l, s_r)
+    y = shamir_gxgxg(ai_commit, ao_commit, s_commit)
+    z = ac_shamir_z(y)
+    ys = power_vector(y, n)
+    zs = power_vector(z, q_len + 1)[1:]
+    zw_l = vector_matrix_product(zs, w_l)
+    zw_r = vector_matrix_product(zs, w_r)
+    zw_o = vector_matrix_product(zs, w_o)
+    y_inv_n = power_vector(pow(y, -1, R), n)
+    # computePolynomials (:104-117)
+    l_poly = [[0] * n, vadd(a_l, hadamard(y_inv_n, zw_r)), a_o, s_l]
+    r_poly = [vsub(zw_o, ys), vadd(hadamard(ys, a_r), zw_l), [0] * n, hadamard(ys, s_r)]
+    t_poly = multiply_poly(l_poly, r_poly)
+    t_blindings = insert_at(2, 0, [0] + [v % R for v in t_randoms])
+    t_commits = [commit(tc, tb) for tc, tb in zip(t_poly, t_blindings)]
+    x = shamir_gs(t_commits)
+    ls = evaluate_polynomial(n, l_poly, x)
+    rs = evaluate_polynomial(n, r_poly, x)
+    t = dot(ls, rs)
+    commit_times_weights = vector_matrix_product_t(witness["commitBlinders"], c["commitmentWeights"])
+    z_gamma = dot(zs, commit_times_weights)
+    t_blinding = (sum(b * pow(x, i, R) for i, b in enumerate(t_blindings)) + x * x * z_gamma) % R
+    mu = (ai_blinding * x + ao_blinding * x * x + s_blinding * pow(x, 3, R)) % R
+    u = point_mul(GEN, shamir_u(t_blinding, mu, t))
+    hsp = [point_mul(hi, yi) for hi, yi in zip(hs(n), y_inv_n)]
+    commitment_lr = ac_lr_commitment(n, (ai_commit, ao_commit, s_commit), x, y, zw_l, zw_r, zw_o, mu, t, u, hsp)
+    if trace is not None:
+        trace.update(y=y, z=z, x=x, tPoly=t_poly, ls=list(ls), rs=list(rs), P=commitment_lr, u=u)
+    product_proof = ipp_generate_proof(gs(n), hsp, u, commitment_lr, ls, rs)
+    return dict(tBlinding=t_blinding, mu=mu, t=t, aiCommit=ai_commit, aoCommit=ao_commit, sCommit=s_commit,
+                tCommits=t_commits, productProof=product_proof)
+
+
+def ac_verify_proof(v_commits, proof, circuit):
+    """`verifyProof` (ArithmeticCircuit/Verifier.hs:16-71)."""
+    c = pad_circuit(circuit)
+    w_l, w_r, w_o = c["wL"], c["wR"], c["wO"]
+    n = len(w_l[0])
+    q_len = len(w_l)
+    x = shamir_gs(proof["tCommits"])
+    y = shamir_gxgxg(proof["aiCommit"], proof["aoCommit"], proof["sCommit"])
+    z = ac_shamir_z(y)
+    zs = power_vector(z, q_len + 1)[1:]
+    zw_l = vector_matrix_product(zs, w_l)
+    zw_r = vector_matrix_product(zs, w_r)
+    zw_o = vector_matrix_product(zs, w_o)
+    hsp = [point_mul(hi, yi) for hi, yi in zip(hs(n), power_vector(pow(y, -1, R), n))]
+    u = point_mul(GEN, shamir_u(proof["tBlinding"], proof["mu"], proof["t"]))
+    # verifyTPoly (:43-54)
+    lhs = commit(proof["t"], proof["tBlinding"])
+    k = ac_delta(n, y, zw_l, zw_r)
+    c_q = dot(zs, [v % R for v in c["cs"]])
+    g_exp = x * x * (k + c_q) % R
+    v_exp = [x * x * v % R for v in vector_matrix_product(zs, c["commitmentWeights"])]
+    xs = [0, x, 0] + [pow(x, e, R) for e in range(3, 7)]
+    rhs = point_add(point_add(point_mul(GEN, g_exp), sum_exps(xs, proof["tCommits"])), sum_exps(v_exp, v_commits))
+    verify_t_poly_ok = lhs == rhs
+    # verifyLRCommitment (:56-71)
+    commitment_lr = ac_lr_commitment(n, (proof["aiCommit"], proof["aoCommit"], proof["sCommit"]), x, y,
+                                     zw_l, zw_r, zw_o, proof["mu"], proof["t"], u, hsp)
+    lr_ok = ipp_verify_proof(n, gs(n), hsp, u, commitment_lr, proof["productProof"])
+    return lr_ok and verify_t_poly_ok
+
+
+def ac_draw_blinders(rng, n):
+    """Test stand-in for MonadRandom in the AC prover's draw order and ranges
+    (ArithmeticCircuit/Prover.hs:24-27,32,57; Utils.hs:135-139).  n = padded gate count."""
+    three = [rng.randint(1, R - 1) for _ in range(3)]
+    s_l = [rng.randint(1, 2**n - 1) % R for _ in range(n)] if n else []
+    s_r = [rng.randint(1, 2**n - 1) % R for _ in range(n)] if n else []
+    five = [rng.randint(1, R - 1) for _ in range(5)]
+    return (*three, s_l, s_r, five)

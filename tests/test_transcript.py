@@ -72,3 +72,19 @@ def test_portable_sha_path_matches():
     raw = bytes(range(256)) * 5
     assert int(out[0]) == int.from_bytes(hashlib.sha256(raw).digest(), "big") % R
     assert int(out[1]) == int.from_bytes(hashlib.sha256(b"abc").digest(), "big") % P
+
+
+def test_circuit_shamir_functions(style):
+    """ArithmeticCircuit/Internal.hs:109-117: shamirGxGxG, shamirGs (with `O` among the points, as
+    tCommits[0] = commit 0 0 always is) and the one-argument shamirZ."""
+    rng = random.Random(20 + style)
+    for it in range(10):
+        a, b, c = (rand_point(rng) for _ in range(3))
+        y = rng.randrange(R)
+        assert _lib.transcript(style, 7, [a, b, c]) == o.shamir_gxgxg(a, b, c)
+        assert _lib.transcript(style, 8, [], [y]) == o.ac_shamir_z(y)
+        ps = [None] + [rand_point(rng) for _ in range(6)]
+        if it == 1:
+            ps[2] = None
+        assert _lib.transcript(style, 9, ps, raw=b"\0" * len(ps)) == o.shamir_gs(ps)
+    assert _lib.transcript(style, 9, [], raw=b"") == o.shamir_gs([])
