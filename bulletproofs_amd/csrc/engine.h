@@ -65,6 +65,7 @@ struct bp_ctx {
   uint32_t n_bases = 0;      // rows of d_bases: gs, hs, G, H, GS_k
   uint8_t* d_bases = nullptr;  // affine, 64 B each
   uint8_t* d_table = nullptr;  // fixed-base window table, see fixedbase.h
+  int fb_wbits = 8;            // window width of d_table (8, 12 or 16), chosen in bp_ctx_set_generators
   // transcript conventions the reference inherits from un-vendored packages
   int show_style = 0;    // 0: derived Show "A (P x) (P y)" / "P s"; 1: plain "A x y" / "s"
   int sqrt_branch = 0;   // 0: sr returns a^((p+1)/4); 1: the other root

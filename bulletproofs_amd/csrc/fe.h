@@ -106,6 +106,20 @@ BP_HD void mac96(uint64_t& acc, uint32_t& ext, uint32_t a, uint32_t b) {
 #endif
 }
 
+// First product of a column: acc(64) += a*b and ext(32) = carry, without reading ext.
+BP_HD void mac96_first(uint64_t& acc, uint32_t& ext, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "+v"(acc), "=v"(ext)
+      : "v"(a), "v"(b)
+      : "vcc");
+#else
+  uint64_t p = (uint64_t)a * b;
+  acc += p;
+  ext = (acc < p) ? 1u : 0u;
+#endif
+}
+
 // 8x8 -> 16 limb schoolbook product, row-wise (operand scanning).  Kept as the
 // A/B arm of benchmarks/microbench.hip.
 BP_HD void mul_wide_rows(uint32_t t[16], const u256& a, const u256& b) {
@@ -130,10 +144,275 @@ BP_HD void mul_wide_rows(uint32_t t[16], const u256& a, const u256& b) {
   }
 }
 
-// 8x8 -> 16 limb product, column-wise (product scanning) into a 96-bit
-// accumulator: the 64-bit addend of v_mad_u64_u32 is the accumulator itself, so
-// no zero-extension moves are needed, and the carry-out feeds one v_addc.
+// ---- carry chains as single asm blocks (device): one VALU instruction per limb, carry in VCC ----
+#if defined(__HIP_DEVICE_COMPILE__)
+// r[0..7] += s[0..7]; returns the carry out (0/1)
+__device__ __forceinline__ uint32_t dev_add8(uint32_t* r, const uint32_t* s) {
+  uint32_t co = 0;
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %16, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, 0, %8, vcc"
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(co)
+      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7])
+      : "vcc");
+  return co;
+}
+// r[0] += x0, r[1] += x1, then the carry ripples through r[2..7]; returns the carry out
+__device__ __forceinline__ uint32_t dev_add2_ripple8(uint32_t* r, uint32_t x0, uint32_t x1) {
+  uint32_t co = 0;
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
+      "v_addc_co_u32 %8, vcc, 0, %8, vcc"
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(co)
+      : "v"(x0), "v"(x1)
+      : "vcc");
+  return co;
+}
+// r[0] += x0, r[1] += x1, carry ripples through r[2..7] (no carry out kept: callers bound the value)
+__device__ __forceinline__ void dev_add2_ripple8_nc(uint32_t* r, uint32_t x0, uint32_t x1) {
+  asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, 0, %7, vcc"
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+      : "v"(x0), "v"(x1)
+      : "vcc");
+}
+#endif
+
+// 8x8 -> 16 limb product, column-wise (product scanning) into 96-bit accumulators: the 64-bit
+// addend of v_mad_u64_u32 is the accumulator itself, so no zero-extension moves are needed, and
+// the carry-out feeds one v_addc.  On the device the low columns (0..7) and the high columns
+// (8..14) run as two interleaved, independent chains - a dependent v_mad_u64_u32 otherwise
+// waits on its predecessor - and the low chain's final carry is rippled into the high limbs.
 BP_HD void mul_wide(uint32_t t[16], const u256& a, const u256& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE_PORTABLE_MUL)
+  // generated by benchmarks/gen_fe_schedule.py mul: low chain = columns 0..7 (36 products), high chain =
+  // columns 8..14 (28 products), one product of each in turn, one asm block per run between column ends
+  uint64_t accL = 0, accH = 0;
+  uint32_t extL, extH;
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "+v"(accL), "=&v"(extL)
+      : "v"(a.v[0]), "v"(b.v[0])
+      : "vcc");
+  t[0] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %4, %10, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+      : "+v"(accH), "=&v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[6]), "v"(b.v[0])
+      : "vcc");
+  t[1] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %10, %11, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %14, %15, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+      : "+v"(accH), "+v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[0])
+      : "vcc");
+  t[2] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "+v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[1])
+      : "vcc");
+  t[8] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %9, %10, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %11, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[7]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[6]), "v"(b.v[0])
+      : "vcc");
+  t[3] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %7, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %9, %10, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %11, %10, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %12, %13, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %14, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "+v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[5]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[6]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[7])
+      : "vcc");
+  t[9] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %4, %6, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[3]), "v"(b.v[1]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[0])
+      : "vcc");
+  t[4] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %7, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %9, %10, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %11, %10, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %12, %13, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %14, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "+v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[6]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[7])
+      : "vcc");
+  t[10] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %9, %10, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %11, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[7]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[6]), "v"(b.v[0])
+      : "vcc");
+  t[5] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "+v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[4])
+      : "vcc");
+  t[11] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %10, %11, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %14, %5, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+      : "+v"(accL), "+v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[7])
+      : "vcc");
+  t[12] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %10, %11, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+      : "+v"(accL), "+v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[6])
+      : "vcc");
+  t[13] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL)
+      : "v"(a.v[6]), "v"(b.v[0])
+      : "vcc");
+  t[6] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "+v"(accH), "=&v"(extH)
+      : "v"(a.v[7]), "v"(b.v[7])
+      : "vcc");
+  t[14] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "=&v"(extL)
+      : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0])
+      : "vcc");
+  t[7] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  t[15] = (uint32_t)accH;
+  dev_add2_ripple8_nc(t + 8, (uint32_t)accL, (uint32_t)(accL >> 32));  // the product is < 2^512: no carry out
+#else
   uint64_t acc = 0;
   uint32_t ext = 0;
 #pragma unroll
@@ -147,10 +426,159 @@ BP_HD void mul_wide(uint32_t t[16], const u256& a, const u256& b) {
     ext = 0;
   }
   t[15] = (uint32_t)acc;
+#endif
 }
 
 // 8 -> 16 limb square: off-diagonal products once, doubled, plus the diagonal.
 BP_HD void sqr_wide(uint32_t t[16], const u256& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE_PORTABLE_SQR)
+  // off-diagonal column sums S_k = sum_{i<j, i+j=k} a_i a_j, k = 1..13, as two interleaved chains
+  // (columns 1..7 and 8..13), exactly as in mul_wide
+  // generated by benchmarks/gen_fe_schedule.py sqr
+  uint64_t accL = 0, accH = 0;
+  uint32_t extL, extH;
+  uint32_t o[16];
+  o[0] = 0;
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "+v"(accL), "=&v"(extL)
+      : "v"(a.v[0]), "v"(a.v[1])
+      : "vcc");
+  o[1] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc"
+      : "+v"(accH), "=&v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[1]), "v"(a.v[7]), "v"(a.v[0]), "v"(a.v[2])
+      : "vcc");
+  o[2] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "+v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[2]), "v"(a.v[6]), "v"(a.v[0]), "v"(a.v[3]), "v"(a.v[5])
+      : "vcc");
+  o[8] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL)
+      : "v"(a.v[1]), "v"(a.v[2])
+      : "vcc");
+  o[3] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %10, %8, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+      : "+v"(accH), "=&v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[2]), "v"(a.v[7]), "v"(a.v[0]), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[6]), "v"(a.v[1])
+      : "vcc");
+  o[4] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "+v"(extH)
+      : "v"(a.v[4]), "v"(a.v[5])
+      : "vcc");
+  o[9] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %9, %10, %2\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+      : "+v"(accL), "=&v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[0]), "v"(a.v[5]), "v"(a.v[3]), "v"(a.v[7]), "v"(a.v[1]), "v"(a.v[4]), "v"(a.v[6])
+      : "vcc");
+  o[10] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL)
+      : "v"(a.v[2]), "v"(a.v[3])
+      : "vcc");
+  o[5] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %7, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accH), "=&v"(extH), "+v"(accL), "=&v"(extL)
+      : "v"(a.v[4]), "v"(a.v[7]), "v"(a.v[0]), "v"(a.v[6]), "v"(a.v[5])
+      : "vcc");
+  o[11] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %2, vcc, %5, %6, %2\n\t"
+      "v_addc_co_u32_e64 %3, vcc, 0, 0, vcc"
+      : "+v"(accL), "+v"(extL), "+v"(accH), "=&v"(extH)
+      : "v"(a.v[1]), "v"(a.v[5]), "v"(a.v[7])
+      : "vcc");
+  o[12] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "+v"(extL)
+      : "v"(a.v[2]), "v"(a.v[4])
+      : "vcc");
+  o[6] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "+v"(accH), "=&v"(extH)
+      : "v"(a.v[6]), "v"(a.v[7])
+      : "vcc");
+  o[13] = (uint32_t)accH;
+  accH = (accH >> 32) | ((uint64_t)extH << 32);
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(accL), "=&v"(extL)
+      : "v"(a.v[0]), "v"(a.v[7]), "v"(a.v[1]), "v"(a.v[6]), "v"(a.v[2]), "v"(a.v[5]), "v"(a.v[3]), "v"(a.v[4])
+      : "vcc");
+  o[7] = (uint32_t)accL;
+  accL = (accL >> 32) | ((uint64_t)extL << 32);
+  o[14] = (uint32_t)accH;
+  o[15] = (uint32_t)(accH >> 32);
+  dev_add2_ripple8_nc(o + 8, (uint32_t)accL, (uint32_t)(accL >> 32));
+  // double
+#pragma unroll
+  for (int i = 15; i > 0; i--) t[i] = (o[i] << 1) | (o[i - 1] >> 31);
+  t[0] = 0;
+  // add the diagonal squares (independent products), as two 8-limb carry chains
+  uint32_t d[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t sq = (uint64_t)a.v[i] * a.v[i];
+    d[2 * i] = (uint32_t)sq;
+    d[2 * i + 1] = (uint32_t)(sq >> 32);
+  }
+  uint32_t c = dev_add8(t, d);
+  d[8] += c;  // the low word of a square is never 2^32 - 1 (-1 is not a square mod 4): no overflow
+  (void)dev_add8(t + 8, d + 8);  // a^2 < 2^512: no carry out
+#else
   uint64_t c;
   t[0] = 0;
   // off-diagonal: sum_{i<j} a_i a_j 2^(32(i+j)), rows i = 0..6
@@ -188,6 +616,7 @@ BP_HD void sqr_wide(uint32_t t[16], const u256& a) {
     t[2 * i + 1] = (uint32_t)c;
     c >>= 32;
   }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -202,9 +631,9 @@ BP_HD u256 fq_p() {
   return p;
 }
 
-// r += k * C for k in {0,1}, r known to be < C-ish after a wrap: touches 3 limbs.
+// r += k * C for a small k (0..3), r known to be tiny after a wrap past 2^256: touches 3 limbs.
 BP_HD void fq_fold_small(u256& r, uint32_t k) {
-  uint64_t c = (uint64_t)r.v[0] + (k ? 977u : 0u);
+  uint64_t c = (uint64_t)r.v[0] + k * 977u;
   r.v[0] = (uint32_t)c;
   c >>= 32;
   c += (uint64_t)r.v[1] + k;
@@ -263,6 +692,50 @@ BP_HD u256 fq_dbl(const u256& a) { return fq_add(a, a); }
 
 // Fold a 512-bit product to a weakly reduced 256-bit value.
 BP_HD u256 fq_reduce_wide(const uint32_t t[16]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE_PORTABLE_REDUCE)
+  // lo + hi * C, C = 2^32 + 977: eight independent products hi_i * 977, then three carry chains
+  uint32_t a[9], plo[8], phi[8], hi[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t pr = (uint64_t)t[8 + i] * 977u;
+    plo[i] = (uint32_t)pr;
+    phi[i] = (uint32_t)(pr >> 32);  // < 2^10
+    a[i] = t[i];
+    hi[i] = t[8 + i];
+  }
+  a[8] = dev_add8(a, plo);          // a[0..8] = lo + sum plo_i 2^(32 i)
+  (void)dev_add8(a + 1, phi);       // + sum phi_i 2^(32 (i+1)): a[8] <= 2^10 + 1, no carry out
+  uint32_t a9 = dev_add8(a + 1, hi);  // + hi << 32
+  // second fold: h2 = a9:a[8] < 2^33; add h2 * 977 at limb 0 and h2 at limb 1
+  uint64_t w = (uint64_t)a[8] * 977u + (a9 ? 977ull << 32 : 0ull);
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = a[i];
+  uint32_t k = dev_add2_ripple8(r.v, (uint32_t)w, (uint32_t)(w >> 32));
+  uint32_t r1[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) r1[i] = r.v[i + 1];
+  // r.v[1..7] += (a[8], a9) with ripple: reuse the 8-limb chain on limbs 1..7 plus a scratch top
+  {
+    uint32_t co = 0;
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, 0, %7, vcc"
+        : "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]), "+v"(r1[4]), "+v"(r1[5]), "+v"(r1[6]), "+v"(co)
+        : "v"(a[8]), "v"(a9)
+        : "vcc");
+    k += co;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; i++) r.v[i + 1] = r1[i];
+  fq_fold_small(r, k);
+  return r;
+#else
   uint32_t a[10];
   // a = lo + hi*977
   uint64_t c = 0;
@@ -302,6 +775,7 @@ BP_HD u256 fq_reduce_wide(const uint32_t t[16]) {
   }
   fq_fold_small(r, (uint32_t)c);
   return r;
+#endif
 }
 
 BP_HD u256 fq_mul(const u256& a, const u256& b) {

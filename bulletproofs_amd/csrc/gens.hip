@@ -2,6 +2,7 @@
 // lazy CAF lists `gs`, `hs` and the points `h`, `gen`
 // (/root/reference/Bulletproofs/Utils.hs:14-25), plus the fixed-base window
 // tables (fixedbase.h) used by the batch verifier and by bp_commit.
+#include <stdlib.h>
 #include "engine.h"
 #include "devio.h"
 #include "fixedbase.h"
@@ -20,54 +21,83 @@ __global__ void __launch_bounds__(256) k_gsum(const uint8_t* __restrict__ gs, ui
   st_affine(out + (size_t)k * 64, xyzz_to_affine(acc));
 }
 
-// start[b][w] = 2^(8w) * bases[b] in XYZZ; one thread per base
-__global__ void __launch_bounds__(256) k_fb_starts(const uint8_t* __restrict__ bases, uint32_t nbases,
+// start[b][w] = 2^(wb*w) * bases[b] in XYZZ; one thread per base
+__global__ void __launch_bounds__(256) k_fb_starts(const uint8_t* __restrict__ bases, uint32_t nbases, int wb,
                                                   xyzz* __restrict__ starts) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbases) return;
+  const int W = fb_windows(wb);
   xyzz cur = xyzz_from_affine(ld_affine(bases + (size_t)b * 64));
-  for (int w = 0; w < FB_WINDOWS; w++) {
-    st_xyzz(&starts[(size_t)b * FB_WINDOWS + w], cur);
-    if (w + 1 < FB_WINDOWS)
-      for (int i = 0; i < FB_WBITS; i++) cur = xyzz_dbl(cur);
+  for (int w = 0; w < W; w++) {
+    st_xyzz(&starts[(size_t)b * W + w], cur);
+    if (w + 1 < W)
+      for (int i = 0; i < wb; i++) cur = xyzz_dbl(cur);
   }
 }
 
-// table[(b*33 + w)*128 + d-1] = d * start[b][w], affine.  One thread per (b, w):
-// 127 XYZZ additions, then one shared inversion for the 128 entries
-// (Montgomery's trick, with the prefix products parked in the output rows).
-__global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts, uint32_t nrows,
-                                                xyzz* __restrict__ scratch, uint8_t* __restrict__ table) {
-  uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= nrows) return;
+// table[(row * E + d - 1)] = d * start[row], affine, for rows [row0, row0 + nrows), E = 2^(wb-1) entries each.
+// One thread per (row, block of `blk` consecutive d): a short double-and-add to the block's first
+// multiple, blk - 1 XYZZ additions, then one shared inversion for the block (Montgomery's trick, with
+// the prefix products parked in the output slots).  scratch[(j * nthreads + t)] keeps the block's
+// XYZZ values, strided so that lanes coalesce.
+__global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts, uint32_t row0, uint32_t nrows,
+                                                uint32_t entries, uint32_t blk, xyzz* __restrict__ scratch,
+                                                uint8_t* __restrict__ table) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t per_row = entries / blk;
+  uint32_t nthreads = nrows * per_row;
+  if (t >= nthreads) return;
+  uint32_t row = row0 + t / per_row, part = t % per_row;
   xyzz s = ld_xyzz(&starts[row]);
-  xyzz* tmp = scratch + (size_t)row * FB_ENTRIES;
-  uint8_t* out = table + (size_t)row * FB_ENTRIES * 64;
-  bool inf = xyzz_is_inf(s);
-  // entries in XYZZ
-  xyzz cur = s;
-  for (int d = 0; d < FB_ENTRIES; d++) {
-    st_xyzz(&tmp[d], cur);
-    cur = xyzz_add(cur, s);
-  }
-  if (inf) {
-    for (int d = 0; d < FB_ENTRIES; d++) st_affine(out + (size_t)d * 64, affine_inf());
+  uint8_t* out = table + ((size_t)row * entries + (size_t)part * blk) * 64;
+  if (xyzz_is_inf(s)) {
+    for (uint32_t d = 0; d < blk; d++) st_affine(out + (size_t)d * 64, affine_inf());
     return;
   }
-  // prefix products of ZZZ (d*S is never the identity for d <= 128 < r)
+  // first = (part * blk + 1) * s
+  xyzz cur = xyzz_inf();
+  uint32_t first = part * blk + 1;
+  for (int bit = 15; bit >= 0; bit--) {
+    cur = xyzz_dbl(cur);
+    if ((first >> bit) & 1u) cur = xyzz_add(cur, s);
+  }
+  for (uint32_t d = 0; d < blk; d++) {
+    st_xyzz(&scratch[(size_t)d * nthreads + t], cur);
+    cur = xyzz_add(cur, s);
+  }
+  // prefix products of ZZZ (d*S is never the identity for d <= 2^15 < r)
   u256 run = u256_one();
-  for (int d = 0; d < FB_ENTRIES; d++) {
+  for (uint32_t d = 0; d < blk; d++) {
     st_u256(out + (size_t)d * 64, run);  // product of ZZZ_0..ZZZ_{d-1}
-    run = fq_mul(run, ld_u256(&tmp[d].ZZZ));
+    run = fq_mul(run, ld_u256(&scratch[(size_t)d * nthreads + t].ZZZ));
   }
   u256 inv = fq_inv(run);
-  for (int d = FB_ENTRIES - 1; d >= 0; d--) {
-    xyzz e = ld_xyzz(&tmp[d]);
+  for (int d = (int)blk - 1; d >= 0; d--) {
+    xyzz e = ld_xyzz(&scratch[(size_t)d * nthreads + t]);
     u256 pre = ld_u256(out + (size_t)d * 64);
     u256 zi = fq_mul(inv, pre);  // 1 / ZZZ_d
     inv = fq_mul(inv, e.ZZZ);
     st_affine(out + (size_t)d * 64, xyzz_to_affine_with_inv(e, zi));
   }
+}
+
+// window width for a generator set: the widest whose table fits the budget (env BP_FB_WBITS forces one)
+static int choose_fb_wbits(uint32_t nbases) {
+  if (const char* e = getenv("BP_FB_WBITS")) {
+    int v = atoi(e);
+    if (v == 8 || v == 12 || v == 16) return v;
+  }
+  size_t budget = (size_t)24 << 30;
+  if (const char* e = getenv("BP_FB_TABLE_GIB")) {
+    long v = atol(e);
+    if (v >= 1 && v <= 200) budget = (size_t)v << 30;
+  }
+  const int cand[3] = {16, 12, 8};
+  for (int wb : cand) {
+    size_t bytes = (size_t)nbases * fb_windows(wb) * fb_entries(wb) * 64;
+    if (bytes <= budget) return wb;
+  }
+  return 8;
 }
 
 }  // namespace bp
@@ -86,9 +116,11 @@ int bp_ctx_set_generators(bp_ctx* ctx, const uint8_t* gs, const uint8_t* hs, con
   while ((1u << nk) < n_gens) nk++;
   nk += 1;  // GS_k for k = 0..log2(n_gens)
   uint32_t nbases = 2 * n_gens + 2 + nk;
-  size_t nrows = (size_t)nbases * FB_WINDOWS;
-  size_t table_bytes = nrows * FB_ENTRIES * 64;
-  Carver cv(nullptr);
+  const int wb = choose_fb_wbits(nbases);
+  const uint32_t W = fb_windows(wb), E = fb_entries(wb);
+  const uint32_t blk = E < (uint32_t)FB_BUILD_BLOCK ? E : (uint32_t)FB_BUILD_BLOCK;
+  size_t nrows = (size_t)nbases * W;
+  size_t table_bytes = nrows * E * 64;
   auto carve = [&](void* base) {
     Carver c(base);
     ctx->d_bases = c.take<uint8_t>((size_t)nbases * 64);
@@ -110,18 +142,26 @@ int bp_ctx_set_generators(bp_ctx* ctx, const uint8_t* gs, const uint8_t* hs, con
   BP_TRY(hipStreamSynchronize(st));  // G lives on the host stack
   hipLaunchKernelGGL(k_gsum, dim3(1), dim3(256), 0, st, ctx->d_bases, n_gens, nk,
                      ctx->d_bases + (size_t)(2 * n_gens + 2) * 64);
-  // temporary buffers for the build
+  // temporary buffers for the build: window starts + XYZZ scratch for one slab of rows (<= 2 GiB)
+  size_t row_scratch = (size_t)E * sizeof(xyzz);
+  size_t slab_rows = ((size_t)2 << 30) / row_scratch;
+  if (slab_rows < 1) slab_rows = 1;
+  if (slab_rows > nrows) slab_rows = nrows;
   DevBuf tmp;
-  size_t tmp_bytes = nrows * sizeof(xyzz) + 256 + nrows * FB_ENTRIES * sizeof(xyzz);
-  if (tmp.reserve(tmp_bytes) != 0) {
+  size_t starts_bytes = (nrows * sizeof(xyzz) + 255) & ~(size_t)255;
+  if (tmp.reserve(starts_bytes + slab_rows * row_scratch) != 0) {
     ctx->err = "generator table scratch allocation failed";
     return BP_ERR_NOMEM;
   }
   xyzz* starts = (xyzz*)tmp.p;
-  xyzz* scratch = (xyzz*)((char*)tmp.p + ((nrows * sizeof(xyzz) + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(k_fb_starts, dim3((nbases + 255) / 256), dim3(256), 0, st, ctx->d_bases, nbases, starts);
-  hipLaunchKernelGGL(k_fb_fill, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, starts, (uint32_t)nrows,
-                     scratch, ctx->d_table);
+  xyzz* scratch = (xyzz*)((char*)tmp.p + starts_bytes);
+  hipLaunchKernelGGL(k_fb_starts, dim3((nbases + 255) / 256), dim3(256), 0, st, ctx->d_bases, nbases, wb, starts);
+  for (size_t r0 = 0; r0 < nrows; r0 += slab_rows) {
+    uint32_t nr = (uint32_t)(nrows - r0 < slab_rows ? nrows - r0 : slab_rows);
+    size_t nthreads = (size_t)nr * (E / blk);
+    hipLaunchKernelGGL(k_fb_fill, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, starts, (uint32_t)r0, nr,
+                       E, blk, scratch, ctx->d_table);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   tmp.release();
@@ -129,6 +169,7 @@ int bp_ctx_set_generators(bp_ctx* ctx, const uint8_t* gs, const uint8_t* hs, con
     ctx->err = std::string("generator table build: ") + hipGetErrorString(e);
     return BP_ERR_DEVICE;
   }
+  ctx->fb_wbits = wb;
   ctx->n_gens = n_gens;
   ctx->n_bases = nbases;
   return BP_OK;

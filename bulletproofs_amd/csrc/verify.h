@@ -12,6 +12,7 @@ struct VDims {
   uint32_t m;   // aggregated values (power of two; commitments padded with O)
   uint32_t nm;  // vector length
   uint32_t k;   // IPP rounds = log2(nm)
+  uint32_t wb;  // window width of the context's fixed-base table (fixedbase.h)
 };
 
 // rows of the per-batch point array pts[row][proof][64]

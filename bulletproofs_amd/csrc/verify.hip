@@ -29,11 +29,21 @@ enum { C_Y = 0, C_Z, C_X, C_U, C_YINV, C_X2, C_DELTA, C_S0, C_COUNT };
 __device__ __forceinline__ u256 ldm(const u256* a, size_t idx) { return ld_u256(a + idx); }
 __device__ __forceinline__ void stm(u256* a, size_t idx, const u256& v) { st_u256(a + idx, v); }
 
-__device__ __forceinline__ void put_digits(uint32_t* dig, uint32_t term, uint32_t B, uint32_t p, const u256& k_canon) {
-  uint32_t d[FB_DWORDS];
-  fb_recode(k_canon, d);
+template <int WB>
+__device__ __forceinline__ void put_digits_w(uint32_t* dig, uint32_t term, uint32_t B, uint32_t p, const u256& k_canon) {
+  uint32_t d[fb_dwords(WB)];
+  fb_recode<WB>(k_canon, d);
 #pragma unroll
-  for (int g = 0; g < FB_DWORDS; g++) dig[((size_t)term * FB_DWORDS + g) * B + p] = d[g];
+  for (int g = 0; g < fb_dwords(WB); g++) dig[((size_t)term * fb_dwords(WB) + g) * B + p] = d[g];
+}
+// digits of one term for the context's window width (uniform branch)
+__device__ __forceinline__ void put_digits(uint32_t* dig, uint32_t term, const VDims& d, uint32_t p, const u256& k_canon) {
+  if (d.wb == 16)
+    put_digits_w<16>(dig, term, d.B, p, k_canon);
+  else if (d.wb == 12)
+    put_digits_w<12>(dig, term, d.B, p, k_canon);
+  else
+    put_digits_w<8>(dig, term, d.B, p, k_canon);
 }
 
 // thread per proof: challenges -> Montgomery constants, y^-i ladder, z powers, delta
@@ -99,43 +109,55 @@ __global__ void __launch_bounds__(256) k_vprep1(VDims d, const uint8_t* __restri
   u256 c = Fr::mul(Fr::mul(ldm(zpow, (size_t)(j + 2) * B + p), Fr::to_mont(Fr::reduce_once(two_k))),
                    ldm(ypowinv, (size_t)i * B + p));
   c = Fr::add(c, z);
-  put_digits(dig, i, d.B, p, Fr::from_mont(c));
+  put_digits(dig, i, d, p, Fr::from_mont(c));
   if (i == 0) {
     u256 mu = Fr::reduce_once(ld_u256(sc + ((size_t)1 * B + p) * 32));
     u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
-    put_digits(dig, d.nm + 0, d.B, p, Fr::from_mont(Fr::neg(z)));                         // -z  * GS
-    put_digits(dig, d.nm + 1, d.B, p, Fr::neg(mu));                                       // -mu * H  (canonical neg)
-    put_digits(dig, d.nm + 2, d.B, p, Fr::from_mont(Fr::mul(tt, ldm(cst, C_U * B + p))));  // t*u * G
+    put_digits(dig, d.nm + 0, d, p, Fr::from_mont(Fr::neg(z)));                         // -z  * GS
+    put_digits(dig, d.nm + 1, d, p, Fr::neg(mu));                                       // -mu * H  (canonical neg)
+    put_digits(dig, d.nm + 2, d, p, Fr::from_mont(Fr::mul(tt, ldm(cst, C_U * B + p))));  // t*u * G
   }
 }
 
 // ---- fixed-base multi-exponentiation: acc[p] = sum_terms k[term][p] * base(term) ---------
 // lpp lanes cooperate on one proof (terms strided over them) and are summed by shuffles.
+// The table entry of the next non-zero digit is fetched before the current mixed add is
+// issued, so the (HBM-resident for 12/16-bit windows) gather overlaps the field arithmetic.
+template <int WB>
 __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nterms, uint32_t lpp,
                                                        const uint32_t* __restrict__ dig,
                                                        const uint32_t* __restrict__ term_base,
                                                        const uint8_t* __restrict__ table, xyzz* __restrict__ acc_out) {
+  constexpr int W = fb_windows(WB), E = fb_entries(WB), DW = fb_dwords(WB), SLOT = fb_slot_bits(WB), PER = 32 / SLOT;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t p = t / lpp, sub = t % lpp;
   bool live = p < B;
   xyzz acc = xyzz_inf();
   if (live) {
+    affine pend = affine_inf();  // fetched, not yet added
+    bool pend_neg = false, have = false;
     for (uint32_t term = sub; term < nterms; term += lpp) {
-      const uint8_t* rows = table + (size_t)term_base[term] * FB_WINDOWS * FB_ENTRIES * 64;
-      for (int g = 0; g < FB_DWORDS; g++) {
-        uint32_t word = dig[((size_t)term * FB_DWORDS + g) * B + p];
+      const uint8_t* rows = table + (size_t)term_base[term] * W * E * 64;
+#pragma unroll 1
+      for (int g = 0; g < DW; g++) {
+        uint32_t word = dig[((size_t)term * DW + g) * B + p];
         if (word == 0) continue;
-        for (int b = 0; b < 4; b++) {
-          uint32_t code = (word >> (8 * b)) & 0xFFu;
+#pragma unroll 1
+        for (int b = 0; b < PER; b++) {
+          uint32_t code = (word >> (SLOT * b)) & ((1u << SLOT) - 1u);
           if (code == 0) continue;
-          int w = 4 * g + b;
-          bool neg = code > 0x80u;
-          uint32_t mag = neg ? 256u - code : code;
-          affine q = ld_affine(rows + ((size_t)w * FB_ENTRIES + (mag - 1)) * 64);
-          bucket_add(acc, q, neg);
+          int w = PER * g + b;
+          bool neg;
+          uint32_t mag = fb_decode<WB>(code, neg);
+          affine q = ld_affine(rows + ((size_t)w * E + (mag - 1)) * 64);
+          if (have) bucket_add(acc, pend, pend_neg);
+          pend = q;
+          pend_neg = neg;
+          have = true;
         }
       }
     }
+    if (have) bucket_add(acc, pend, pend_neg);
   }
   for (uint32_t dlt = lpp >> 1; dlt > 0; dlt >>= 1) {
     xyzz o = shfl_down_xyzz(acc, dlt);
@@ -240,16 +262,16 @@ __global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restri
     if ((i >> j) & 1u) s = Fr::mul(s, Fr::sqr(ldm(xk_m, (size_t)(d.k - 1 - j) * B + p)));
   u256 l = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)3 * B + p) * 32)));
   u256 r = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)4 * B + p) * 32)));
-  put_digits(dig_a, i, d.B, p, Fr::from_mont(Fr::mul(l, s)));
+  put_digits(dig_a, i, d, p, Fr::from_mont(Fr::mul(l, s)));
   uint32_t hi = d.nm - 1 - i;
-  put_digits(dig_a, d.nm + hi, d.B, p, Fr::from_mont(Fr::mul(Fr::mul(r, s), ldm(ypowinv, (size_t)hi * B + p))));
+  put_digits(dig_a, d.nm + hi, d, p, Fr::from_mont(Fr::mul(Fr::mul(r, s), ldm(ypowinv, (size_t)hi * B + p))));
   if (i == 0) {
     u256 u = ldm(cst, C_U * B + p);
-    put_digits(dig_a, 2 * d.nm, d.B, p, Fr::from_mont(Fr::mul(Fr::mul(l, r), u)));  // (l r u) G
+    put_digits(dig_a, 2 * d.nm, d, p, Fr::from_mont(Fr::mul(Fr::mul(l, r), u)));  // (l r u) G
     u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
     u256 tau = Fr::reduce_once(ld_u256(sc + ((size_t)0 * B + p) * 32));
-    put_digits(dig_b, 0, d.B, p, Fr::from_mont(Fr::sub(tt, ldm(cst, C_DELTA * B + p))));  // (t - delta) G
-    put_digits(dig_b, 1, d.B, p, tau);                                                    // tau H
+    put_digits(dig_b, 0, d, p, Fr::from_mont(Fr::sub(tt, ldm(cst, C_DELTA * B + p))));  // (t - delta) G
+    put_digits(dig_b, 1, d, p, tau);                                                    // tau H
     for (uint32_t j = 0; j < d.m; j++)
       st_u256(vs + ((size_t)j * B + p) * 32, Fr::from_mont(Fr::neg(ldm(zpow, (size_t)(j + 2) * B + p))));
     st_u256(vs + ((size_t)d.m * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X * B + p))));
@@ -303,12 +325,24 @@ namespace bp {
 static inline void prof_begin(bp_vbatch* vb, int slot, uint32_t nterms) {
   if (!vb->ctx->profile) return;
   (void)hipEventRecord(vb->ev[slot][0], vb->stream);
-  vb->ev_madds[slot] = (double)vb->d.B * nterms * 32.0;  // 8-bit windows over 256 bits
+  // one mixed add per non-zero digit: 256 / wb windows per term
+  vb->ev_madds[slot] = (double)vb->d.B * nterms * (256.0 / vb->d.wb);
 }
 static inline void prof_end(bp_vbatch* vb, int slot) {
   if (!vb->ctx->profile) return;
   (void)hipEventRecord(vb->ev[slot][1], vb->stream);
   vb->ev_pending[slot] = true;
+}
+
+static inline void launch_fixed(bp_vbatch* vb, size_t nthreads, uint32_t nterms, uint32_t lpp, const uint32_t* dig,
+                                const uint32_t* tb, xyzz* acc) {
+  const uint8_t* table = vb->ctx->d_table;
+  if (vb->d.wb == 16)
+    hipLaunchKernelGGL(k_fixed_multiexp<16>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+  else if (vb->d.wb == 12)
+    hipLaunchKernelGGL(k_fixed_multiexp<12>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+  else
+    hipLaunchKernelGGL(k_fixed_multiexp<8>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
 }
 
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
@@ -333,7 +367,7 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   uint32_t lpp = vbatch_lpp(d.B);
   prof_begin(vb, 0, vb->nt1);
-  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt1, lpp, vb->dig1, vb->tb1, ctx->d_table, vb->acc1);
+  launch_fixed(vb, B * lpp, vb->nt1, lpp, vb->dig1, vb->tb1, vb->acc1);
   prof_end(vb, 0);
   hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff);
   BP_TRY(hipGetLastError());
@@ -371,11 +405,10 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
                      vb->dig3a, vb->dig3b, vb->vs);
   uint32_t lpp = vbatch_lpp(d.B);
   prof_begin(vb, 1, vb->nt3a);
-  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B * lpp), d.B, vb->nt3a, lpp, vb->dig3a, vb->tb3a, ctx->d_table,
-                     vb->acc1);
+  launch_fixed(vb, B * lpp, vb->nt3a, lpp, vb->dig3a, vb->tb3a, vb->acc1);
   prof_end(vb, 1);
   prof_begin(vb, 2, vb->nt3b);
-  hipLaunchKernelGGL(k_fixed_multiexp, VB_GRID(B), d.B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, ctx->d_table, vb->acc2);
+  launch_fixed(vb, B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, vb->acc2);
   prof_end(vb, 2);
   uint32_t nv = d.m + 2;
   uint32_t j = 0;
@@ -435,6 +468,8 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   d.nm = nm;
   d.k = 0;
   while ((1u << d.k) < nm) d.k++;
+  d.wb = (uint32_t)ctx->fb_wbits;
+  const size_t DW = fb_dwords(ctx->fb_wbits);
   vb->npts = VP_L0 + 2 * d.k + m;
   vb->nt1 = nm + 3;
   vb->nt3a = 2 * nm + 1;
@@ -454,9 +489,9 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->zpow = c.take<u256>((size_t)(m + 3) * B);
     vb->xk_m = c.take<u256>((size_t)(d.k ? d.k : 1) * B);
     vb->xkinv_m = c.take<u256>((size_t)(d.k ? d.k : 1) * B);
-    vb->dig1 = c.take<uint32_t>((size_t)vb->nt1 * FB_DWORDS * B);
-    vb->dig3a = c.take<uint32_t>((size_t)vb->nt3a * FB_DWORDS * B);
-    vb->dig3b = c.take<uint32_t>((size_t)vb->nt3b * FB_DWORDS * B);
+    vb->dig1 = c.take<uint32_t>((size_t)vb->nt1 * DW * B);
+    vb->dig3a = c.take<uint32_t>((size_t)vb->nt3a * DW * B);
+    vb->dig3b = c.take<uint32_t>((size_t)vb->nt3b * DW * B);
     vb->tb1 = c.take<uint32_t>(vb->nt1);
     vb->tb3a = c.take<uint32_t>(vb->nt3a);
     vb->tb3b = c.take<uint32_t>(vb->nt3b);
