@@ -25,6 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
 
+# more hardware queues than HIP's default of 4, before anything initialises the HIP runtime: the verifier's
+# chunk streams only overlap when they share a hardware pipe (bulletproofs_amd/csrc/ctx.hip)
+if not os.environ.get("BP_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(256) k_busy(uint32_t* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 int main() {
-  const int NS = 4;
+  const int NS = 8;
   hipStream_t st[NS];
   uint32_t* d[NS];
   uint8_t* h[NS];
@@ -38,6 +38,21 @@ int main() {
       if (rep) printf("%-44s streams=%d blocks/stream=%d copies=%d : %.3f ms\n", label, ns, blocks, (int)copies, ms);
     }
   };
+  // which pairs of streams overlap?  (streams map onto a few hardware queues / pipes)
+  for (int a = 0; a < NS; a++)
+    for (int b = a + 1; b < NS; b++) {
+      double best = 1e9;
+      for (int rep = 0; rep < 2; rep++) {
+        auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_busy, dim3(128), dim3(256), 0, st[a], d[a], 300);
+        hipLaunchKernelGGL(k_busy, dim3(128), dim3(256), 0, st[b], d[b], 300);
+        (void)hipStreamSynchronize(st[a]);
+        (void)hipStreamSynchronize(st[b]);
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms < best) best = ms;
+      }
+      printf("pair (%d,%d): %.3f ms\n", a, b, best);
+    }
   run(1, 64, false, "one small kernel");
   run(4, 64, false, "four small kernels on four streams");
   run(1, 256, false, "one kernel with 4x the blocks");

@@ -2,6 +2,22 @@
 import ctypes
 import os
 
+# The batch verifier overlaps its chunks on streams that share a hardware pipe; HIP's default of 4
+# hardware queues per process leaves no such pair ("streams").  Must be set before the HIP
+# runtime initialises.  Values below 8 (HIP's default is 4) are raised to 16 unless BP_KEEP_HW_QUEUES is set.
+def _want_hw_queues():
+    if os.environ.get("BP_KEEP_HW_QUEUES"):
+        return
+    try:
+        cur = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        cur = 4
+    if cur < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
+
+_want_hw_queues()
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbpgpu.so")
 

@@ -1,5 +1,93 @@
 // Context management and host-pointer staging for the C ABI (include/bpgpu.h).
+#include <stdlib.h>
+#include <chrono>
+
 #include "engine.h"
+
+namespace bp {
+
+// ---- streams that really overlap ---------------------------------------------------------------
+// Measured on MI355X (benchmarks/concurrency_test2.hip): a field-arithmetic kernel saturates a SIMD
+// with a single wave, so two kernels that each fill part of the chip only run side by side when
+// their workgroups land on different CUs.  Dispatches from hardware queues of different pipes all
+// start filling from the same CUs (two 128-workgroup kernels then take twice as long as one);
+// dispatches from queues of the same pipe continue where the previous one stopped.  With HIP's
+// default of 4 hardware queues per process every stream has a pipe of its own; with 8 or more,
+// streams 4 apart share one.  The latency-bound per-round kernels of the batch verifier need that
+// side-by-side placement, so the context keeps a pool of streams and finds, by timing a small
+// VALU-bound kernel alone and in pairs, a set whose members run concurrently.
+__global__ void __launch_bounds__(256) k_spin(uint32_t* out, int iters) {
+  u256 a = u256_one(), b = u256_one();
+  a.v[0] = threadIdx.x + 3;
+  b.v[1] = blockIdx.x + 5;
+  for (int i = 0; i < iters; i++) {
+    a = fq_mul(a, b);
+    b = fq_mul(b, a);
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= a.v[i] ^ b.v[i];
+  if (s == 0x12345u) out[0] = s;  // keeps the loop alive
+}
+
+static double spin_ms(hipStream_t a, hipStream_t b, uint32_t* d_out, int iters) {
+  double best = 1e30;
+  for (int rep = 0; rep < 2; rep++) {
+    auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, a, d_out, iters);
+    if (b) hipLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, b, d_out, iters);
+    (void)hipStreamSynchronize(a);
+    if (b) (void)hipStreamSynchronize(b);
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+
+static void build_stream_pool(bp_ctx* ctx) {
+  const int P = 16;
+  for (int i = 0; i < P; i++) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+    ctx->spool.push_back(s);
+  }
+  ctx->sgroup.clear();
+  uint32_t* d_out = nullptr;
+  if (ctx->spool.size() < 2 || hipMalloc(&d_out, 256) != hipSuccess) {
+    for (size_t i = 0; i < ctx->spool.size(); i++) ctx->sgroup.push_back((int)i);
+    return;
+  }
+  const int iters = 300;  // ~0.25 ms
+  (void)spin_ms(ctx->spool[0], nullptr, d_out, 4);  // code object load
+  for (size_t base = 0; base < 4 && base + 1 < ctx->spool.size(); base++) {
+    double t1 = spin_ms(ctx->spool[base], nullptr, d_out, iters);
+    std::vector<int> grp{(int)base};
+    for (size_t j = base + 1; j < ctx->spool.size(); j++) {
+      double t2 = spin_ms(ctx->spool[base], ctx->spool[j], d_out, iters);
+      if (getenv("BP_TRACE")) fprintf(stderr, "[ctx] spin base %zu: alone %.3f ms, with %zu %.3f ms\n", base, t1, j, t2);
+      if (t2 < 1.5 * t1) grp.push_back((int)j);
+    }
+    if (grp.size() > ctx->sgroup.size()) ctx->sgroup = grp;
+    if (ctx->sgroup.size() >= 2) break;
+  }
+  (void)hipFree(d_out);
+  if (getenv("BP_TRACE")) {
+    fprintf(stderr, "[ctx] stream pool: %zu streams, concurrent set {", ctx->spool.size());
+    for (int g : ctx->sgroup) fprintf(stderr, " %d", g);
+    fprintf(stderr, " }\n");
+  }
+  if (ctx->sgroup.size() < 2) {  // nothing overlaps (e.g. 4 hardware queues): any streams will do
+    ctx->sgroup.clear();
+    for (size_t i = 0; i < ctx->spool.size(); i++) ctx->sgroup.push_back((int)i);
+  }
+}
+
+hipStream_t ctx_chunk_stream(bp_ctx* ctx) {
+  if (ctx->spool.empty()) build_stream_pool(ctx);
+  if (ctx->sgroup.empty()) return ctx->stream;
+  return ctx->spool[ctx->sgroup[ctx->spool_next++ % ctx->sgroup.size()]];
+}
+
+}  // namespace bp
 
 extern "C" {
 
@@ -8,6 +96,12 @@ int bp_version(void) { return 100; }
 int bp_ctx_create(bp_ctx** out, int device) {
   if (!out) return BP_ERR_ARG;
   *out = nullptr;
+  // more hardware queues than HIP's default of 4, so that chunk streams can share a pipe (see above);
+  // only effective if the HIP runtime has not been initialised yet; BP_KEEP_HW_QUEUES leaves the setting alone
+  if (!getenv("BP_KEEP_HW_QUEUES")) {
+    const char* cur = getenv("GPU_MAX_HW_QUEUES");
+    if (!cur || atoi(cur) < 8) setenv("GPU_MAX_HW_QUEUES", "16", 1);
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return BP_ERR_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return BP_ERR_DEVICE;
@@ -33,6 +127,7 @@ void bp_ctx_destroy(bp_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int i = 0; i < 2; i++)
     if (ctx->msm_ev[i]) (void)hipEventDestroy(ctx->msm_ev[i]);
+  for (hipStream_t s : ctx->spool) (void)hipStreamDestroy(s);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

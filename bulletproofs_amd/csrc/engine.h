@@ -65,6 +65,10 @@ struct bp_ctx {
   uint32_t n_bases = 0;      // rows of d_bases: gs, hs, G, H, GS_k
   uint8_t* d_bases = nullptr;  // affine, 64 B each
   uint8_t* d_table = nullptr;  // fixed-base window table, see fixedbase.h
+  // streams for the batch verifier's chunks: a set that the hardware runs concurrently (ctx.hip)
+  std::vector<hipStream_t> spool;
+  std::vector<int> sgroup;  // indices into spool that overlap with each other
+  size_t spool_next = 0;
   int fb_wbits = 8;            // window width of d_table (8, 12 or 16), chosen in bp_ctx_set_generators
   // transcript conventions the reference inherits from un-vendored packages
   int show_style = 0;    // 0: derived Show "A (P x) (P y)" / "P s"; 1: plain "A x y" / "s"
@@ -97,6 +101,8 @@ struct bp_ctx {
 
 namespace bp {
 // msm.hip
+// A stream for one chunk of a batch job, from the context's concurrent set (round-robin).  Not owned by the caller.
+hipStream_t ctx_chunk_stream(bp_ctx* ctx);
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz);
 // ipp.hip (device pointers, asynchronous on ctx->stream)

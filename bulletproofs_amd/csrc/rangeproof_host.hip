@@ -195,6 +195,7 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     ch.xk = cv.take<uint8_t>(B * 32);
     ch.acc = cv.take<uint8_t>(B * 64);
     ch.verdict = cv.take<uint8_t>(B);
+    ch.vb->direct_host = true;  // acc / verdict above are pinned: the kernels store to them directly
   }
   *out = job;
   return BP_OK;

@@ -45,6 +45,8 @@ struct bp_vbatch {
   bp::xyzz *acc1, *acc2, *vtab;
   uint32_t nt1, nt3a, nt3b, npts;
   int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
+  // outputs of the *_async calls are pinned host memory the kernels may store to directly
+  bool direct_host;
   // profiling: event pairs around the three k_fixed_multiexp launches
   hipEvent_t ev[3][2];
   bool ev_pending[3];

@@ -202,7 +202,8 @@ __device__ __forceinline__ xyzz glv_multiexp_dev(const u256 (&k)[NP], const affi
 // stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
                                                     const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
-                                                    xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/) {
+                                                    xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/,
+                                                    uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
@@ -211,14 +212,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   xyzz acc = glv_multiexp_dev<1>(k, P, tab, B, p);
   acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
   acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
-  st_affine(acc_aff + (size_t)p * 64, xyzz_to_affine(acc));
+  affine out = xyzz_to_affine(acc);
+  st_affine(acc_aff + (size_t)p * 64, out);
+  if (host_out) st_affine(host_out + (size_t)p * 64, out);
 }
 
 // one IPP round of mkChallenges: acc <- x^2 L + x^-2 R + acc  (Verifier.hs:47-50)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_round(VDims d, uint32_t round, const uint8_t* __restrict__ pts,
                                               const uint8_t* __restrict__ xk /*[B][32] canonical*/,
                                               u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
-                                              xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff) {
+                                              xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff,
+                                              uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
@@ -231,7 +235,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                  ld_affine(pts + ((size_t)(VP_L0 + d.k + round) * B + p) * 64)};
   xyzz acc = glv_multiexp_dev<2>(k, P, tab, B, p);
   acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
-  st_affine(acc_aff + (size_t)p * 64, xyzz_to_affine(acc));
+  affine out = xyzz_to_affine(acc);
+  st_affine(acc_aff + (size_t)p * 64, out);
+  if (host_out) st_affine(host_out + (size_t)p * 64, out);
 }
 
 // thread per proof: s0 = prod_k x_k^-1  (mkOtherExponents, Verifier.hs:59)
@@ -305,12 +311,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 
 // verdict[p] = (acc1 == acc_k) && (acc2 == O)
 __global__ void __launch_bounds__(256) k_verdict(VDims d, const xyzz* __restrict__ acc1, const xyzz* __restrict__ acc2,
-                                                const uint8_t* __restrict__ acc_aff, uint8_t* __restrict__ verdict) {
+                                                const uint8_t* __restrict__ acc_aff, uint8_t* __restrict__ verdict,
+                                                uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   xyzz e1 = xyzz_madd(ld_xyzz(&acc1[p]), affine_neg(ld_affine(acc_aff + (size_t)p * 64)));
   bool ok = xyzz_is_inf(e1) && xyzz_is_inf(ld_xyzz(&acc2[p]));
   verdict[p] = ok ? 1 : 0;
+  if (host_out) host_out[p] = ok ? 1 : 0;
 }
 
 }  // namespace bp
@@ -369,9 +377,13 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   prof_begin(vb, 0, vb->nt1);
   launch_fixed(vb, B * lpp, vb->nt1, lpp, vb->dig1, vb->tb1, vb->acc1);
   prof_end(vb, 0);
-  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff);
+  // A device-to-host copy command after the kernel would serialise the chunks' streams against each
+  // other (measured: benchmarks/concurrency_test3.hip); with pinned outputs the kernel stores its
+  // result to host memory itself.
+  uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
+  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct);
   BP_TRY(hipGetLastError());
-  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
+  if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
   return BP_OK;
 }
@@ -385,9 +397,11 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   VDims d = vb->d;
   size_t B = d.B;
   BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, vb->stream));
-  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff);
+  uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
+  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff,
+                     direct);
   BP_TRY(hipGetLastError());
-  BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
+  if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage++;
   return BP_OK;
 }
@@ -417,9 +431,10 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
     j = 3;
   }
   for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->vtab, vb->acc2);
-  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict);
+  uint8_t* direct = vb->direct_host ? verdicts : nullptr;
+  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict, direct);
   BP_TRY(hipGetLastError());
-  BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
+  if (!direct) BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 1;  // may be begun again with the same loaded proofs
   return BP_OK;
 }
@@ -501,7 +516,8 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     return c.off;
   };
   size_t need = carve(nullptr);
-  hipError_t e = hipStreamCreateWithFlags(&vb->stream, hipStreamNonBlocking);
+  vb->stream = ctx_chunk_stream(ctx);  // from the context's concurrent set; not owned
+  hipError_t e = hipSuccess;
   for (int s2 = 0; s2 < 3; s2++) {
     vb->ev_pending[s2] = false;
     vb->ev[s2][0] = vb->ev[s2][1] = nullptr;
@@ -509,7 +525,6 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][1]);
   }
   if (e != hipSuccess || vb->buf.reserve(need) != 0) {
-    if (vb->stream) (void)hipStreamDestroy(vb->stream);
     delete vb;
     ctx->err = "verifier workspace allocation failed";
     return BP_ERR_NOMEM;
@@ -535,12 +550,12 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   if (e == hipSuccess) e = hipStreamSynchronize(vb->stream);
   if (e != hipSuccess) {
     vb->buf.release();
-    (void)hipStreamDestroy(vb->stream);
     delete vb;
     ctx->err = std::string("bp_vbatch_create: ") + hipGetErrorString(e);
     return BP_ERR_DEVICE;
   }
   vb->stage = 0;
+  vb->direct_host = false;
   *out = vb;
   return BP_OK;
 }
@@ -553,7 +568,6 @@ void bp_vbatch_destroy(bp_vbatch* vb) {
   for (int s = 0; s < 3; s++)
     for (int j = 0; j < 2; j++)
       if (vb->ev[s][j]) (void)hipEventDestroy(vb->ev[s][j]);
-  (void)hipStreamDestroy(vb->stream);
   delete vb;
 }
 
