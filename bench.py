@@ -179,6 +179,19 @@ def main():
     eng.profile(False)
     for v in results:
         got = check(v)
+    # The chunks of the timed pipeline overlap on purpose, so the event-timed duration of one
+    # k_fixed_multiexp launch above includes time shared with other chunks' kernels.  One extra untimed
+    # pass with a single chunk gives the same kernel's duration with the GPU to itself.
+    iso = None
+    if rank == 0:
+        job1 = eng.vjob(n_bits, 1, B, 1, a.host_threads)
+        job1.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
+        check(job1.run())
+        eng.profile(True)
+        check(job1.run())
+        iso = eng.profile_read(0)
+        eng.profile(False)
+        job1.close()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -206,7 +219,7 @@ def main():
                 "proofs_per_gpu": B, "bits": n_bits, "m": 1,
                 "host_threads": a.host_threads or int(os.environ.get("BP_HOST_THREADS", "0")) or
                 min(16, os.cpu_count() or 1),
-                "chunks": a.chunks or (2 if B >= 4096 else 1),
+                "chunks": a.chunks or (4 if B >= 16384 else (2 if B >= 4096 else 1)),
                 "proofgen_s": gen_s,
             },
         }
@@ -223,11 +236,20 @@ def main():
                 "executed_mad_frac_of_peak": ach * 74.0 / 136.0 / PEAK_TMAD,
                 "traffic": None,
             }
+            if iso and iso[1]:
+                iso_ach = iso[2] * MODMUL_PER_MADD * MADS_PER_MODMUL / (iso[0] * 1e-3) / 1e12
+                line["roofline"]["isolated"] = {
+                    "what": "same kernel, one untimed single-chunk pass after the timed region (no other kernel "
+                            "shares the GPU)",
+                    "launches": iso[1], "avg_launch_ms": iso[0] / iso[1], "achieved": iso_ach,
+                    "frac": iso_ach / PEAK_TMAD}
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):  # HBM bytes per launch from the separate rocprofv3 --pmc passes (not live)
                 t = json.load(open(tf))
                 line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = t["source"]
+                if "valu_issue_util" in t:  # SQ_INSTS_VALU x 4 cycles against SIMD-cycles of the same launches
+                    line["roofline"]["valu_issue_util"] = t["valu_issue_util"]
         if world == 1:
             if a.cpu_sample > 0:
                 line["cpu_baseline"] = cpu_baseline(sc, pts, n_bits, min(a.cpu_sample, B), got)

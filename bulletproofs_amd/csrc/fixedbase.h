@@ -10,7 +10,8 @@
 // installed: HBM is large (288 GB), so small generator sets get 16-bit windows
 // (17 mixed adds per term, 2 MiB of table per window and base) and large sets fall
 // back to 12- or 8-bit windows.  WB = 8: 33 windows x 128 entries; WB = 12:
-// 22 x 2048; WB = 16: 17 x 32768.
+// 22 x 2048; WB = 16: 17 x 32768; WB = 20: 13 x 524288 (32 MiB per window and base;
+// only taken when the table budget is raised, BP_FB_TABLE_GIB).
 #pragma once
 #include "ec.h"
 
@@ -18,10 +19,10 @@ namespace bp {
 
 BP_HD constexpr int fb_windows(int wb) { return 256 / wb + 1; }
 BP_HD constexpr int fb_entries(int wb) { return 1 << (wb - 1); }  // magnitudes 1..2^(wb-1)
-// digits are packed into u32 words: 4 bytes per word for wb <= 8, else 2 halfwords per word
-BP_HD constexpr int fb_slot_bits(int wb) { return wb <= 8 ? 8 : 16; }
+// digits are packed into u32 words: 4 bytes per word for wb <= 8, 2 halfwords for wb <= 16, else one word each
+BP_HD constexpr int fb_slot_bits(int wb) { return wb <= 8 ? 8 : (wb <= 16 ? 16 : 32); }
 BP_HD constexpr int fb_dwords(int wb) { return (fb_windows(wb) * fb_slot_bits(wb) + 31) / 32; }
-constexpr int FB_MAX_DWORDS = 11;  // wb = 12: 22 halfwords
+constexpr int FB_MAX_DWORDS = 13;  // wb = 20: 13 words
 constexpr int FB_BUILD_BLOCK = 256;  // table entries produced per thread of the build kernel
 
 // base numbering inside the table for a context with `ng` generator pairs
@@ -48,7 +49,8 @@ BP_HD uint32_t fb_window_bits(const u256& k, int lo) {
 template <int WB>
 BP_HD void fb_recode(const u256& k, uint32_t (&out)[fb_dwords(WB)]) {
   constexpr int SLOT = fb_slot_bits(WB), PER = 32 / SLOT, W = fb_windows(WB);
-  constexpr uint32_t HALF = 1u << (WB - 1), FULL = 1u << WB, SMASK = SLOT == 32 ? 0xFFFFFFFFu : ((1u << SLOT) - 1u);
+  constexpr uint32_t HALF = 1u << (WB - 1), FULL = 1u << WB;
+  constexpr uint32_t SMASK = SLOT == 32 ? 0xFFFFFFFFu : (uint32_t)((1ull << SLOT) - 1ull);
   uint32_t carry = 0;
 #pragma unroll
   for (int g = 0; g < fb_dwords(WB); g++) {
@@ -78,7 +80,8 @@ BP_HD uint32_t fb_decode(uint32_t code, bool& neg) {
   constexpr uint32_t HALF = 1u << (WB - 1);
   // negative digits are stored as 2^SLOT - mag with mag < HALF, i.e. code > 2^SLOT - HALF
   neg = code > HALF;
-  return neg ? (1u << SLOT) - code : code;
+  constexpr uint32_t SMASK = SLOT == 32 ? 0xFFFFFFFFu : (uint32_t)((1ull << SLOT) - 1ull);
+  return neg ? ((0u - code) & SMASK) : code;
 }
 
 }  // namespace bp

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts
   // first = (part * blk + 1) * s
   xyzz cur = xyzz_inf();
   uint32_t first = part * blk + 1;
-  for (int bit = 15; bit >= 0; bit--) {
+  for (int bit = 19; bit >= 0; bit--) {
     cur = xyzz_dbl(cur);
     if ((first >> bit) & 1u) cur = xyzz_add(cur, s);
   }
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts
     st_xyzz(&scratch[(size_t)d * nthreads + t], cur);
     cur = xyzz_add(cur, s);
   }
-  // prefix products of ZZZ (d*S is never the identity for d <= 2^15 < r)
+  // prefix products of ZZZ (d*S is never the identity for d <= 2^19 < r)
   u256 run = u256_one();
   for (uint32_t d = 0; d < blk; d++) {
     st_u256(out + (size_t)d * 64, run);  // product of ZZZ_0..ZZZ_{d-1}
@@ -85,14 +85,14 @@ __global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts
 static int choose_fb_wbits(uint32_t nbases) {
   if (const char* e = getenv("BP_FB_WBITS")) {
     int v = atoi(e);
-    if (v == 8 || v == 12 || v == 16) return v;
+    if (v == 8 || v == 12 || v == 16 || v == 20) return v;
   }
-  size_t budget = (size_t)24 << 30;
+  size_t budget = (size_t)64 << 30;  // of 288 GB HBM3E
   if (const char* e = getenv("BP_FB_TABLE_GIB")) {
     long v = atol(e);
     if (v >= 1 && v <= 200) budget = (size_t)v << 30;
   }
-  const int cand[3] = {16, 12, 8};
+  const int cand[4] = {20, 16, 12, 8};
   for (int wb : cand) {
     size_t bytes = (size_t)nbases * fb_windows(wb) * fb_entries(wb) * 64;
     if (bytes <= budget) return wb;

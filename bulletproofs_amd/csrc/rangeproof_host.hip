@@ -153,7 +153,8 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
   BP_REQUIRE(out, "null pointer");
   *out = nullptr;
   BP_REQUIRE(batch >= 1, "batch must be >= 1");
-  if (n_chunks == 0) n_chunks = batch >= 4096 ? 2 : 1;
+  // chunks ping-pong between host hashing and the GPU; four streams of the context's concurrent set overlap
+  if (n_chunks == 0) n_chunks = batch >= 16384 ? 4 : (batch >= 4096 ? 2 : 1);
   BP_REQUIRE(n_chunks <= 64 && n_chunks <= batch, "n_chunks out of range");
   BP_TRY(hipSetDevice(ctx->device));
   bp_vjob* job = new bp_vjob();

@@ -1,6 +1,7 @@
 // Shared definitions of the batch verifier (verify.hip, host/rangeproof_host.cpp).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include "engine.h"
 #include "fixedbase.h"
 
@@ -23,8 +24,13 @@ enum { VS_TAU = 0, VS_MU = 1, VS_T = 2, VS_L = 3, VS_R = 4 };
 
 // lanes cooperating on one proof in the fixed-base kernel: enough threads to fill the chip
 inline uint32_t vbatch_lpp(uint32_t B) {
+  static const uint64_t target = [] {
+    const char* e = getenv("BP_FIXED_LANES");
+    uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+    return v ? v : (uint64_t)131072;
+  }();
   uint32_t lpp = 1;
-  while (lpp < 64 && (uint64_t)B * lpp < 131072) lpp <<= 1;
+  while (lpp < 64 && (uint64_t)B * lpp < target) lpp <<= 1;
   return lpp;
 }
 

@@ -38,7 +38,9 @@ __device__ __forceinline__ void put_digits_w(uint32_t* dig, uint32_t term, uint3
 }
 // digits of one term for the context's window width (uniform branch)
 __device__ __forceinline__ void put_digits(uint32_t* dig, uint32_t term, const VDims& d, uint32_t p, const u256& k_canon) {
-  if (d.wb == 16)
+  if (d.wb == 20)
+    put_digits_w<20>(dig, term, d.B, p, k_canon);
+  else if (d.wb == 16)
     put_digits_w<16>(dig, term, d.B, p, k_canon);
   else if (d.wb == 12)
     put_digits_w<12>(dig, term, d.B, p, k_canon);
@@ -134,8 +136,9 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
   bool live = p < B;
   xyzz acc = xyzz_inf();
   if (live) {
-    affine pend = affine_inf();  // fetched, not yet added
-    bool pend_neg = false, have = false;
+    affine p0 = affine_inf(), p1 = affine_inf();  // fetched, not yet added (two gathers in flight)
+    bool n0 = false, n1 = false;
+    int cnt = 0;
     for (uint32_t term = sub; term < nterms; term += lpp) {
       const uint8_t* rows = table + (size_t)term_base[term] * W * E * 64;
 #pragma unroll 1
@@ -144,20 +147,32 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
         if (word == 0) continue;
 #pragma unroll 1
         for (int b = 0; b < PER; b++) {
-          uint32_t code = (word >> (SLOT * b)) & ((1u << SLOT) - 1u);
+          uint32_t code = SLOT == 32 ? word : ((word >> ((SLOT * b) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
           if (code == 0) continue;
           int w = PER * g + b;
           bool neg;
           uint32_t mag = fb_decode<WB>(code, neg);
           affine q = ld_affine(rows + ((size_t)w * E + (mag - 1)) * 64);
-          if (have) bucket_add(acc, pend, pend_neg);
-          pend = q;
-          pend_neg = neg;
-          have = true;
+          if (cnt == 2) {
+            bucket_add(acc, p0, n0);
+            p0 = p1;
+            n0 = n1;
+            p1 = q;
+            n1 = neg;
+          } else if (cnt == 1) {
+            p1 = q;
+            n1 = neg;
+            cnt = 2;
+          } else {
+            p0 = q;
+            n0 = neg;
+            cnt = 1;
+          }
         }
       }
     }
-    if (have) bucket_add(acc, pend, pend_neg);
+    if (cnt >= 1) bucket_add(acc, p0, n0);
+    if (cnt == 2) bucket_add(acc, p1, n1);
   }
   for (uint32_t dlt = lpp >> 1; dlt > 0; dlt >>= 1) {
     xyzz o = shfl_down_xyzz(acc, dlt);
@@ -345,7 +360,9 @@ static inline void prof_end(bp_vbatch* vb, int slot) {
 static inline void launch_fixed(bp_vbatch* vb, size_t nthreads, uint32_t nterms, uint32_t lpp, const uint32_t* dig,
                                 const uint32_t* tb, xyzz* acc) {
   const uint8_t* table = vb->ctx->d_table;
-  if (vb->d.wb == 16)
+  if (vb->d.wb == 20)
+    hipLaunchKernelGGL(k_fixed_multiexp<20>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+  else if (vb->d.wb == 16)
     hipLaunchKernelGGL(k_fixed_multiexp<16>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
   else if (vb->d.wb == 12)
     hipLaunchKernelGGL(k_fixed_multiexp<12>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
