@@ -106,6 +106,23 @@ hipStream_t ctx_chunk_stream(bp_ctx* ctx);
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz);
 // ipp.hip (device pointers, asynchronous on ctx->stream)
+// One batch of two-scalar linear combinations: out[i] = ka*a[i] + kb*b[i] (+ c[i] when c != null), i < n.
+// sa / sb, when non-null, give per-lane canonical scalars (32 B each) instead of the shared ka / kb.
+// a / b / c advance by `stride_*` bytes per lane (0 = the same point for every lane).
+struct LinJob {
+  const uint8_t *a, *b, *c;
+  const uint8_t *sa, *sb;
+  uint8_t* out;
+  u256 ka, kb;
+  uint32_t n, stride_a, stride_b, stride_c;
+};
+// up to three jobs in ONE launch (GLV + 15-entry joint table per lane; d_tab: 15 * total lanes XYZZ)
+int ipp_lincomb_jobs(bp_ctx* ctx, const LinJob* jobs, int njobs, xyzz* d_tab);
+// up to four independent direct MSMs in ONE launch: segment s holds n[s] terms at offset s * stride
+// (stride a multiple of 256) of d_scalars / d_points; d_out: nseg affine points.  n[s] <= msm_direct_limit().
+int msm_direct_multi(bp_ctx* ctx, const uint8_t* d_scalars, const uint8_t* d_points, uint32_t stride, const uint32_t* n,
+                     int nseg, uint8_t* d_out);
+size_t msm_direct_limit();
 int ipp_fold_points(bp_ctx* ctx, const uint8_t* d_lo, const uint8_t* d_hi, uint32_t n, const uint8_t s_lo[32],
                     const uint8_t s_hi[32], xyzz* d_tab, uint8_t* d_out);
 int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, const uint8_t* d_p2, const uint8_t k0[32],

@@ -79,6 +79,51 @@ __global__ void __launch_bounds__(256) k_scale_points(const uint8_t* __restrict_
   st_affine(out + (size_t)i * 64, xyzz_to_affine(acc));
 }
 
+__device__ __forceinline__ void lincomb_lane(const LinJob& j, uint32_t i, xyzz* __restrict__ tab, size_t T, size_t t) {
+  auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * T + t], v); };
+  auto load = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * T + t]); };
+  u256 ka = j.sa ? Fr::reduce_once(ld_u256(j.sa + (size_t)i * 32)) : j.ka;
+  u256 kb = j.sb ? Fr::reduce_once(ld_u256(j.sb + (size_t)i * 32)) : j.kb;
+  HalfPair h0 = glv_prep_point(ka, ld_affine(j.a + (size_t)i * j.stride_a), 1, 2, store);
+  HalfPair h1 = glv_prep_point(kb, ld_affine(j.b + (size_t)i * j.stride_b), 4, 8, store);
+  joint_table_composites<4>(store, load);
+  xyzz acc = xyzz_inf();
+#pragma unroll 1
+  for (int b = 0; b < GLV_BITS; b++) {
+    uint32_t idx = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1) | (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
+    acc = xyzz_dbl(acc);
+    if (idx) acc = xyzz_add(acc, load((int)idx));
+  }
+  if (j.c) acc = xyzz_madd(acc, ld_affine(j.c + (size_t)i * j.stride_c));
+  st_affine(j.out + (size_t)i * 64, xyzz_to_affine(acc));
+}
+
+__global__ void __launch_bounds__(256) k_lincomb_jobs(LinJob j0, LinJob j1, LinJob j2, uint32_t total,
+                                                     xyzz* __restrict__ tab) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  // pick the lane's job by data, not by branch: lanes of different jobs share a wave in the late rounds
+  const bool in0 = t < j0.n, in1 = t < j0.n + j1.n;
+  LinJob j = in0 ? j0 : (in1 ? j1 : j2);
+  uint32_t i = in0 ? t : (in1 ? t - j0.n : t - j0.n - j1.n);
+  lincomb_lane(j, i, tab, total, t);
+}
+
+int ipp_lincomb_jobs(bp_ctx* ctx, const LinJob* jobs, int njobs, xyzz* d_tab) {
+  LinJob j[3];
+  memset((void*)j, 0, sizeof(j));
+  uint32_t total = 0;
+  for (int i = 0; i < njobs && i < 3; i++) {
+    j[i] = jobs[i];
+    total += jobs[i].n;
+  }
+  if (total == 0) return BP_OK;
+  hipLaunchKernelGGL(k_lincomb_jobs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, j[0], j[1], j[2], total,
+                     d_tab);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
 int ipp_fold_points(bp_ctx* ctx, const uint8_t* d_lo, const uint8_t* d_hi, uint32_t n, const uint8_t s_lo[32],
                     const uint8_t s_hi[32], xyzz* d_tab, uint8_t* d_out) {
   u256 a, b;

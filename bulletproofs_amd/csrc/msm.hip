@@ -14,8 +14,10 @@
 //   6 k_seg_reduce    running-sum reduction of 32-bucket segments, one lane each
 //   7 k_window_sum    workgroup tree reduction of the segment values of one window
 //   8 k_final         Horner over the windows + affine normalisation
+#include <stdlib.h>
 #include "engine.h"
 #include "devio.h"
+#include "glv.h"
 
 namespace bp {
 
@@ -274,6 +276,101 @@ __global__ void k_store_inf(uint8_t* out_affine, xyzz* out_xyzz) {
   if (out_affine) st_affine(out_affine, affine_inf());
 }
 
+// ---- direct path for small N ----------------------------------------------------------------------
+// Below a few ten thousand terms the bucket method is dominated by its fixed costs (a dozen launches and
+// the single-lane Horner chain of k_final), while one GLV scalar multiplication per lane costs the same
+// 129 doubling steps whether 64 or 65,536 lanes run it.  One lane per term: k*P as k1*P + k2*phi(P) with
+// the three affine table entries (P, phi P, P + phi P) in registers, selected per bit pair without
+// divergent paths; then a shuffle/LDS tree per workgroup and one more workgroup over the partial sums.
+__device__ __forceinline__ affine select3(uint32_t idx, const affine& p1, const affine& p2, const affine& p3) {
+  affine r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.x.v[i] = idx == 1 ? p1.x.v[i] : (idx == 2 ? p2.x.v[i] : (idx == 3 ? p3.x.v[i] : 0u));
+    r.y.v[i] = idx == 1 ? p1.y.v[i] : (idx == 2 ? p2.y.v[i] : (idx == 3 ? p3.y.v[i] : 0u));
+  }
+  return r;
+}
+
+struct SegN {
+  uint32_t n[4];
+};
+// segment s = blockIdx.x / blocks_per_seg owns terms [s * stride, s * stride + n[s])
+__global__ void __launch_bounds__(256) k_direct_terms(const uint8_t* __restrict__ scalars,
+                                                     const uint8_t* __restrict__ points, uint32_t blocks_per_seg,
+                                                     SegN sn, xyzz* __restrict__ partial) {
+  __shared__ xyzz lds[4];
+  uint32_t seg = blockIdx.x / blocks_per_seg;
+  uint32_t local = (blockIdx.x % blocks_per_seg) * blockDim.x + threadIdx.x;
+  uint32_t n = seg == 0 ? sn.n[0] : (seg == 1 ? sn.n[1] : (seg == 2 ? sn.n[2] : sn.n[3]));
+  size_t i = (size_t)seg * blocks_per_seg * blockDim.x + local;
+  xyzz acc = xyzz_inf();
+  if (local < n) {
+    u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)i * 32));
+    affine P = ld_affine(points + (size_t)i * 64);
+    GlvHalf h1, h2;
+    glv_split(k, h1, h2);
+    affine p1 = h1.neg ? affine_neg(P) : P;
+    affine p2 = glv_phi(P);
+    if (h2.neg) p2 = affine_neg(p2);
+    affine p3 = xyzz_to_affine(xyzz_madd(xyzz_from_affine(p1), p2));  // identity stays (0, 0)
+    BitReg a = bitreg_init(h1), b = bitreg_init(h2);
+#pragma unroll 1
+    for (int bit = 0; bit < GLV_BITS; bit++) {
+      uint32_t idx = bitreg_next(a) | (bitreg_next(b) << 1);
+      acc = xyzz_dbl(acc);
+      acc = xyzz_madd(acc, select3(idx, p1, p2, p3));
+    }
+  }
+  xyzz r = block_sum(acc, lds);
+  if (threadIdx.x == 0) st_xyzz(&partial[blockIdx.x], r);
+}
+
+// one workgroup per segment
+__global__ void __launch_bounds__(1024) k_direct_reduce(const xyzz* __restrict__ partial, uint32_t nparts,
+                                                       uint8_t* __restrict__ out_affine, xyzz* __restrict__ out_xyzz) {
+  __shared__ xyzz lds[16];
+  const xyzz* mine = partial + (size_t)blockIdx.x * nparts;
+  xyzz acc = xyzz_inf();
+  for (uint32_t j = threadIdx.x; j < nparts; j += blockDim.x) acc = xyzz_add(acc, ld_xyzz(&mine[j]));
+  xyzz r = block_sum(acc, lds);
+  if (threadIdx.x == 0) {
+    if (out_xyzz) st_xyzz(out_xyzz + blockIdx.x, r);
+    if (out_affine) st_affine(out_affine + (size_t)blockIdx.x * 64, xyzz_to_affine(r));
+  }
+}
+
+static size_t msm_direct_max() {
+  static const size_t v = [] {
+    const char* e = getenv("BP_MSM_DIRECT_MAX");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)65536;
+  }();
+  return v;
+}
+size_t msm_direct_limit() { return msm_direct_max(); }
+
+int msm_direct_multi(bp_ctx* ctx, const uint8_t* d_scalars, const uint8_t* d_points, uint32_t stride, const uint32_t* n,
+                     int nseg, uint8_t* d_out) {
+  BP_REQUIRE(nseg >= 1 && nseg <= 4 && stride % 256 == 0 && stride > 0, "msm_direct_multi: bad segment layout");
+  SegN sn = {{0, 0, 0, 0}};
+  for (int s2 = 0; s2 < nseg; s2++) {
+    BP_REQUIRE(n[s2] <= stride, "msm_direct_multi: segment longer than the stride");
+    sn.n[s2] = n[s2];
+  }
+  uint32_t bps = stride / 256;
+  if (ctx->msm_ws.reserve((size_t)bps * nseg * sizeof(xyzz)) != 0) {
+    ctx->err = "bp_msm: workspace allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  xyzz* partial = (xyzz*)ctx->msm_ws.p;
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_direct_terms, dim3(bps * nseg), dim3(256), 0, st, d_scalars, d_points, bps, sn, partial);
+  hipLaunchKernelGGL(k_direct_reduce, dim3(nseg), dim3(bps > 16 ? 1024 : 64), 0, st, partial, bps, d_out,
+                     (xyzz*)nullptr);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz) {
@@ -286,6 +383,21 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   if (n >= (1ull << 27)) {
     ctx->err = "bp_msm: n must be below 2^27";
     return BP_ERR_ARG;
+  }
+  if (c_override <= 0 && n <= msm_direct_max()) {
+    uint32_t nblk = (uint32_t)((n + 255) / 256);
+    if (ctx->msm_ws.reserve((size_t)nblk * sizeof(xyzz)) != 0) {
+      ctx->err = "bp_msm: workspace allocation failed";
+      return BP_ERR_NOMEM;
+    }
+    xyzz* partial = (xyzz*)ctx->msm_ws.p;
+    SegN sn = {{(uint32_t)n, 0, 0, 0}};
+    hipLaunchKernelGGL(k_direct_terms, dim3(nblk), dim3(256), 0, st, (const uint8_t*)d_scalars, (const uint8_t*)d_points,
+                       nblk, sn, partial);
+    hipLaunchKernelGGL(k_direct_reduce, dim3(1), dim3(nblk > 16 ? 1024 : 64), 0, st, partial, nblk,
+                       (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
+    BP_TRY(hipGetLastError());
+    return BP_OK;
   }
   int c = c_override > 0 ? c_override : msm_choose_c(n);
   if (c < 1 || c > 16) {

@@ -12,10 +12,11 @@ namespace bp {
 struct ProverWs {
   uint8_t *G, *H;    // current generator vectors (affine), n points each
   uint8_t *G2, *H2;  // fold outputs (ping-pong)
-  uint8_t* pts;      // gathered MSM points, up to 2n + 16
-  uint8_t* sc;       // MSM scalars, up to 2n + 16
-  uint8_t* small;    // 16 single points: u, P, L, R, ...; slot 15 = MSM output
-  xyzz* tab;         // 15 * n joint-table scratch
+  uint8_t* pts;      // gathered MSM points: 4 segments of `seg_cap` entries
+  size_t seg_cap;    // entries per segment (multiple of 256, >= 2n + 16 + extra)
+  uint8_t* sc;       // MSM scalars, same layout
+  uint8_t* small;    // 16 single points: u, P, L, R, ...; slots 12..15 = MSM outputs
+  xyzz* tab;         // 15 * (n + 2) joint-table scratch
 };
 
 // carve the workspace for vectors of n points out of ctx->pws (grown on demand); `extra` more gathered terms
@@ -30,6 +31,16 @@ struct MsmSeg {
 // sum_i scalars[i] * P_i over the concatenated segments -> affine result in host memory (synchronous).
 int msm_gather(bp_ctx* ctx, ProverWs& w, const MsmSeg* segs, int n_segs, const std::vector<host::Fr4>& scalars,
                uint8_t out[64]);
+
+// Up to four gathered MSMs in one launch pair (direct path); falls back to one bucket MSM each when a job
+// has more terms than msm_direct_limit().  Results land in jobs[j].out (host memory); synchronous.
+struct MsmJob {
+  const MsmSeg* segs;
+  int nsegs;
+  const std::vector<host::Fr4>* scalars;
+  uint8_t* out;
+};
+int msm_multi(bp_ctx* ctx, ProverWs& w, const MsmJob* jobs, int njobs);
 
 // MSM over [dA (cnt), dB (cnt), single] with scalars [sa[a0..], sb[b0..], s1]
 int msm3(bp_ctx* ctx, ProverWs& w, const uint8_t* dA, const std::vector<host::Fr4>& sa, size_t a0, const uint8_t* dB,

@@ -22,10 +22,11 @@ int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra) {
     w.H = c.take<uint8_t>((size_t)n * 64);
     w.G2 = c.take<uint8_t>((size_t)n * 64);
     w.H2 = c.take<uint8_t>((size_t)n * 64);
-    w.pts = c.take<uint8_t>((size_t)(2 * n + 16 + extra) * 64);
-    w.sc = c.take<uint8_t>((size_t)(2 * n + 16 + extra) * 32);
+    w.seg_cap = (((size_t)2 * n + 16 + extra) + 255) / 256 * 256;
+    w.pts = c.take<uint8_t>(4 * w.seg_cap * 64);
+    w.sc = c.take<uint8_t>(4 * w.seg_cap * 32);
     w.small = c.take<uint8_t>(16 * 64);
-    w.tab = c.take<xyzz>((size_t)15 * (n ? n : 1));
+    w.tab = c.take<xyzz>((size_t)15 * (n + 2));
     return c.off;
   };
   size_t need = carve(nullptr);
@@ -60,6 +61,50 @@ int msm_gather(bp_ctx* ctx, ProverWs& w, const MsmSeg* segs, int n_segs, const s
   if (rc != BP_OK) return rc;
   BP_TRY(hipMemcpyAsync(out, d_out, 64, hipMemcpyDeviceToHost, st));
   BP_TRY(hipStreamSynchronize(st));  // `sc` and host segments are temporaries
+  return BP_OK;
+}
+
+int msm_multi(bp_ctx* ctx, ProverWs& w, const MsmJob* jobs, int njobs) {
+  BP_REQUIRE(njobs >= 1 && njobs <= 4, "msm_multi: 1..4 jobs");
+  size_t longest = 0;
+  for (int j = 0; j < njobs; j++) {
+    size_t total = 0;
+    for (int s2 = 0; s2 < jobs[j].nsegs; s2++) total += jobs[j].segs[s2].count;
+    BP_REQUIRE(total == jobs[j].scalars->size(), "msm_multi: scalar count does not match the segments");
+    BP_REQUIRE(total <= w.seg_cap, "msm_multi: job exceeds the workspace");
+    if (total > longest) longest = total;
+  }
+  if (longest > msm_direct_limit() || longest == 0) {
+    for (int j = 0; j < njobs; j++) {
+      int rc = msm_gather(ctx, w, jobs[j].segs, jobs[j].nsegs, *jobs[j].scalars, jobs[j].out);
+      if (rc != BP_OK) return rc;
+    }
+    return BP_OK;
+  }
+  hipStream_t st = ctx->stream;
+  const uint32_t stride = (uint32_t)((longest + 255) / 256 * 256);
+  uint32_t n[4] = {0, 0, 0, 0};
+  std::vector<uint8_t> sc((size_t)njobs * stride * 32);
+  for (int j = 0; j < njobs; j++) {
+    size_t off = (size_t)j * stride, total = 0;
+    for (int s2 = 0; s2 < jobs[j].nsegs; s2++) {
+      const MsmSeg& sg = jobs[j].segs[s2];
+      if (sg.count)
+        BP_TRY(hipMemcpyAsync(w.pts + (off + total) * 64, sg.pts, sg.count * 64,
+                              sg.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+      total += sg.count;
+    }
+    for (size_t i = 0; i < total; i++) fr_to_bytes((*jobs[j].scalars)[i], &sc[(off + i) * 32]);
+    n[j] = (uint32_t)total;
+  }
+  BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+  uint8_t* d_out = w.small + 12 * 64;
+  int rc = msm_direct_multi(ctx, w.sc, w.pts, stride, n, njobs, d_out);
+  if (rc != BP_OK) return rc;
+  uint8_t res[4 * 64];
+  BP_TRY(hipMemcpyAsync(res, d_out, (size_t)njobs * 64, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  for (int j = 0; j < njobs; j++) memcpy(jobs[j].out, res + 64 * j, 64);
   return BP_OK;
 }
 
@@ -117,10 +162,24 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
       cR = fr_add(cR, fr_mul(ls[h + i], rs[i]));  // dot lsRight rsLeft  (:61)
     }
     uint8_t L[64], R[64];
-    // lCommit = sumExps lsLeft gsRight <> sumExps rsRight hsLeft <> (bH `mul` cL)   (:63-67)
-    if ((rc = msm3(ctx, w, w.G + (size_t)h * 64, ls, 0, w.H, rs, h, h, d_u, cL, L)) != BP_OK) return rc;
-    // rCommit = sumExps lsRight gsLeft <> sumExps rsLeft hsRight <> (bH `mul` cR)   (:69-73)
-    if ((rc = msm3(ctx, w, w.G, ls, h, w.H + (size_t)h * 64, rs, 0, h, d_u, cR, R)) != BP_OK) return rc;
+    {
+      // lCommit = sumExps lsLeft gsRight <> sumExps rsRight hsLeft <> (bH `mul` cL)   (:63-67)
+      // rCommit = sumExps lsRight gsLeft <> sumExps rsLeft hsRight <> (bH `mul` cR)   (:69-73)
+      // both in one launch: two segments of 2h + 1 terms
+      MsmSeg segL[3] = {{w.G + (size_t)h * 64, h, true}, {w.H, h, true}, {d_u, 1, true}};
+      MsmSeg segR[3] = {{w.G, h, true}, {w.H + (size_t)h * 64, h, true}, {d_u, 1, true}};
+      std::vector<Fr4> scL(2 * (size_t)h + 1), scR(2 * (size_t)h + 1);
+      for (uint32_t i = 0; i < h; i++) {
+        scL[i] = ls[i];
+        scL[h + i] = rs[h + i];
+        scR[i] = ls[h + i];
+        scR[h + i] = rs[i];
+      }
+      scL[2 * (size_t)h] = cL;
+      scR[2 * (size_t)h] = cR;
+      MsmJob jobs[2] = {{segL, 3, &scL, L}, {segR, 3, &scR, R}};
+      if ((rc = msm_multi(ctx, w, jobs, 2)) != BP_OK) return rc;
+    }
     Ls.insert(Ls.end(), L, L + 64);
     Rs.insert(Rs.end(), R, R + 64);
     // x = shamirX' commitmentLR lCommit rCommit   (:75)
@@ -135,15 +194,38 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
     fr_to_bytes(xi, xib);
     fr_to_bytes(fr_sqr(x), x2b);
     fr_to_bytes(fr_sqr(xi), xi2b);
-    // gs'' = xInv*gsLeft + x*gsRight ; hs'' = x*hsLeft + xInv*hsRight   (:81-82)
-    if ((rc = ipp_fold_points(ctx, w.G, w.G + (size_t)h * 64, h, xib, xb, w.tab, w.G2)) != BP_OK) return rc;
-    if ((rc = ipp_fold_points(ctx, w.H, w.H + (size_t)h * 64, h, xb, xib, w.tab, w.H2)) != BP_OK) return rc;
-    std::swap(w.G, w.G2);
-    std::swap(w.H, w.H2);
-    // commitmentLR' = x^2 L + xInv^2 R + commitmentLR   (:87-92)
+    // gs'' = xInv*gsLeft + x*gsRight ; hs'' = x*hsLeft + xInv*hsRight   (:81-82) and
+    // commitmentLR' = x^2 L + xInv^2 R + commitmentLR   (:87-92): 2h + 1 lanes of one launch
     BP_TRY(hipMemcpyAsync(d_L, L, 64, hipMemcpyHostToDevice, st));
     BP_TRY(hipMemcpyAsync(d_R, R, 64, hipMemcpyHostToDevice, st));
-    if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_P, x2b, xi2b, w.tab, d_Pn)) != BP_OK) return rc;
+    {
+      LinJob jb[3];
+      memset((void*)jb, 0, sizeof(jb));
+      jb[0].a = w.G;
+      jb[0].b = w.G + (size_t)h * 64;
+      jb[0].out = w.G2;
+      memcpy(jb[0].ka.v, xib, 32);
+      memcpy(jb[0].kb.v, xb, 32);
+      jb[0].n = h;
+      jb[0].stride_a = jb[0].stride_b = 64;
+      jb[1].a = w.H;
+      jb[1].b = w.H + (size_t)h * 64;
+      jb[1].out = w.H2;
+      memcpy(jb[1].ka.v, xb, 32);
+      memcpy(jb[1].kb.v, xib, 32);
+      jb[1].n = h;
+      jb[1].stride_a = jb[1].stride_b = 64;
+      jb[2].a = d_L;
+      jb[2].b = d_R;
+      jb[2].c = d_P;
+      jb[2].out = d_Pn;
+      memcpy(jb[2].ka.v, x2b, 32);
+      memcpy(jb[2].kb.v, xi2b, 32);
+      jb[2].n = 1;
+      if ((rc = ipp_lincomb_jobs(ctx, jb, 3, w.tab)) != BP_OK) return rc;
+    }
+    std::swap(w.G, w.G2);
+    std::swap(w.H, w.H2);
     BP_TRY(hipMemcpyAsync(P, d_Pn, 64, hipMemcpyDeviceToHost, st));
     BP_TRY(hipMemcpyAsync(d_P, d_Pn, 64, hipMemcpyDeviceToDevice, st));
     // ls' = x*lsLeft + xInv*lsRight ; rs' = xInv*rsLeft + x*rsRight   (:84-85) while the GPU folds
@@ -306,8 +388,17 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
   uint8_t* T1 = proof_points + 128;
   uint8_t* T2 = proof_points + 192;
   // commitBitVectors: A = aBlinding*h + <aL, gs> + <aR, hs>, S likewise   (RangeProof/Internal.hs:136-147)
-  if ((rc = msm3(ctx, w, d_gs, aL, 0, d_hs, aR, 0, n_digits, d_h, fr_from_bytes(alpha), A)) != BP_OK) return rc;
-  if ((rc = msm3(ctx, w, d_gs, sLv, 0, d_hs, sRv, 0, nm, d_h, fr_from_bytes(rho), S)) != BP_OK) return rc;
+  {  // both commitments in one launch
+    MsmSeg segA[3] = {{d_gs, n_digits, true}, {d_hs, n_digits, true}, {d_h, 1, true}};
+    MsmSeg segS[3] = {{d_gs, nm, true}, {d_hs, nm, true}, {d_h, 1, true}};
+    std::vector<Fr4> scA(aL), scS(sLv);
+    scA.insert(scA.end(), aR.begin(), aR.end());
+    scA.push_back(fr_from_bytes(alpha));
+    scS.insert(scS.end(), sRv.begin(), sRv.end());
+    scS.push_back(fr_from_bytes(rho));
+    MsmJob jobs[2] = {{segA, 3, &scA, A}, {segS, 3, &scS, S}};
+    if ((rc = msm_multi(ctx, w, jobs, 2)) != BP_OK) return rc;
+  }
   // y, z   (Prover.hs:75-76)
   uint8_t buf[MSG_SCRATCH], keep[MSG_SCRATCH], yb[32], zb[32], xb[32];
   Msg my(buf, style);
@@ -349,18 +440,10 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
   }
   // t1Commit = commit t1 t1Blinding, t2Commit likewise   (Prover.hs:84-85; Utils.hs:84-85)
   {
-    uint8_t e0[64], e1[64], p0[128], p1[128], out[128];
-    fr_to_bytes(t1, e0);
-    fr_to_bytes(t2, e0 + 32);
-    memcpy(e1, tau1, 32);
-    memcpy(e1 + 32, tau2, 32);
-    memcpy(p0, gen_h, 64);
-    memcpy(p0 + 64, gen_h, 64);
-    memcpy(p1, gen_h + 64, 64);
-    memcpy(p1 + 64, gen_h + 64, 64);
-    if ((rc = bp_add_two_mul(ctx, e0, p0, e1, p1, 2, out)) != BP_OK) return rc;
-    memcpy(T1, out, 64);
-    memcpy(T2, out + 64, 64);
+    MsmSeg seg[1] = {{gen_h, 2, false}};
+    std::vector<Fr4> s1{t1, fr_from_bytes(tau1)}, s2{t2, fr_from_bytes(tau2)};
+    MsmJob jobs[2] = {{seg, 1, &s1, T1}, {seg, 1, &s2, T2}};
+    if ((rc = msm_multi(ctx, w, jobs, 2)) != BP_OK) return rc;
   }
   // x   (Prover.hs:88)
   Msg mx(buf, style);
@@ -398,7 +481,12 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
   mu_.fr(proof_scalars + 32);
   mu_.fr(proof_scalars + 64);
   mu_.finish_fr(ub);
-  if ((rc = bp_point_mul(ctx, ub, gen_h, 1, u)) != BP_OK) return rc;
+  {
+    MsmSeg seg[1] = {{gen_h, 1, false}};
+    std::vector<Fr4> s1{fr_from_bytes(ub)};
+    MsmJob jobs[1] = {{seg, 1, &s1, u}};
+    if ((rc = msm_multi(ctx, w, jobs, 1)) != BP_OK) return rc;
+  }
   // hs' = hs_i * recip(y^i)   (Prover.hs:107): one batched inversion on the host, one GLV kernel
   {
     std::vector<uint8_t> sc((size_t)nm * 32);
