@@ -138,6 +138,14 @@ int load_ipp_base(bp_ctx* ctx, ProverWs& w, const Gens& g, const std::vector<Fr4
   return BP_OK;
 }
 
+// u = gen * k as a one-term direct MSM (GLV, 129 steps instead of the 256-step ladder of bp_point_mul)
+int point_mul_gen(bp_ctx* ctx, ProverWs& w, const Gens& g, const uint8_t k[32], uint8_t out[64]) {
+  MsmSeg seg[1] = {{g.d_gen, 1, true}};
+  std::vector<Fr4> s1{fr_from_bytes(k)};
+  MsmJob jobs[1] = {{seg, 1, &s1, out}};
+  return msm_multi(ctx, w, jobs, 1);
+}
+
 int check_dims(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, uint32_t& n2, uint32_t& k) {
   BP_REQUIRE(n <= 8192 && q <= (1u << 20) && m <= (1u << 20), "circuit dimensions out of range");
   if (ctx->n_gens == 0) {
@@ -198,14 +206,18 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   uint8_t* S = proof_points + 128;
   uint8_t* T = proof_points + 192;  // 7 points
   // commitBitVector (Internal.hs:102-107): aiCommit, aoCommit (vR = []), sCommit   (Prover.hs:29-33)
-  if ((rc = msm3(ctx, w, g.d_gs, aL, 0, g.d_hs, aR, 0, n2, g.d_h, aiB, AI)) != BP_OK) return rc;
-  {
-    MsmSeg segs[2] = {{g.d_gs, n2, true}, {g.d_h, 1, true}};
-    std::vector<Fr4> sc(aO);
-    sc.push_back(aoB);
-    if ((rc = msm_gather(ctx, w, segs, 2, sc, AO)) != BP_OK) return rc;
+  {  // the three commitments in one launch
+    MsmSeg segI[3] = {{g.d_gs, n2, true}, {g.d_hs, n2, true}, {g.d_h, 1, true}};
+    MsmSeg segO[2] = {{g.d_gs, n2, true}, {g.d_h, 1, true}};
+    std::vector<Fr4> scI(aL), scO(aO), scS(sL);
+    scI.insert(scI.end(), aR.begin(), aR.end());
+    scI.push_back(aiB);
+    scO.push_back(aoB);
+    scS.insert(scS.end(), sR.begin(), sR.end());
+    scS.push_back(sB);
+    MsmJob jobs[3] = {{segI, 3, &scI, AI}, {segO, 2, &scO, AO}, {segI, 3, &scS, S}};
+    if ((rc = msm_multi(ctx, w, jobs, 3)) != BP_OK) return rc;
   }
-  if ((rc = msm3(ctx, w, g.d_gs, sL, 0, g.d_hs, sR, 0, n2, g.d_h, sB, S)) != BP_OK) return rc;
 
   uint8_t yb[32], zb[32], xb[32];
   challenge_y_z(style, AI, AO, S, yb, zb);
@@ -233,15 +245,25 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   // tBlindings = insertAt 2 0 (0 : five randoms); tCommits = zipWith commit tPoly tBlindings   (Prover.hs:57-58)
   Fr4 tau[7] = {zero, fr_from_bytes(tau5), zero, fr_from_bytes(tau5 + 32), fr_from_bytes(tau5 + 64),
                 fr_from_bytes(tau5 + 96), fr_from_bytes(tau5 + 128)};
-  {
-    uint8_t e0[7 * 32], e1[7 * 32], p0[7 * 64], p1[7 * 64];
+  {  // seven lanes of one GLV kernel: T_i = t_i * gen + tau_i * h
+    uint8_t e[14 * 32];
     for (int i = 0; i < 7; i++) {
-      fr_to_bytes(tc[i], e0 + 32 * i);
-      fr_to_bytes(tau[i], e1 + 32 * i);
-      memcpy(p0 + 64 * i, g.gen_h, 64);
-      memcpy(p1 + 64 * i, g.gen_h + 64, 64);
+      fr_to_bytes(tc[i], e + 32 * i);
+      fr_to_bytes(tau[i], e + 32 * (7 + i));
     }
-    if ((rc = bp_add_two_mul(ctx, e0, p0, e1, p1, 7, T)) != BP_OK) return rc;
+    hipStream_t st = ctx->stream;
+    BP_TRY(hipMemcpyAsync(w.sc, e, sizeof(e), hipMemcpyHostToDevice, st));
+    LinJob jb;
+    memset((void*)&jb, 0, sizeof(jb));
+    jb.a = g.d_gen;
+    jb.b = g.d_h;
+    jb.sa = w.sc;
+    jb.sb = w.sc + 7 * 32;
+    jb.out = w.pts;
+    jb.n = 7;
+    if ((rc = ipp_lincomb_jobs(ctx, &jb, 1, w.tab)) != BP_OK) return rc;
+    BP_TRY(hipMemcpyAsync(T, w.pts, 7 * 64, hipMemcpyDeviceToHost, st));
+    BP_TRY(hipStreamSynchronize(st));
   }
   challenge_x(style, T, xb);
   const Fr4 x = fr_from_bytes(xb), x2 = fr_sqr(x), x3 = fr_mul(x2, x);
@@ -274,7 +296,7 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   // u = gen * shamirU tBlinding mu t   (:74-75)
   uint8_t ub[32], u[64];
   challenge_u(style, proof_scalars, ub);
-  if ((rc = bp_point_mul(ctx, ub, g.gen_h, 1, u)) != BP_OK) return rc;
+  if ((rc = point_mul_gen(ctx, w, g, ub, u)) != BP_OK) return rc;
   if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
   // commitmentLR (:77-85).  Expanding aiCommit, aoCommit, sCommit and mu, the same group element is
   // <ls, gs> + <rs, hs'> + t*u for the prover's own ls, rs (an identity in the exponents, no
@@ -336,7 +358,7 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   fr_to_bytes(mu, canon3 + 32);
   fr_to_bytes(t, canon3 + 64);
   challenge_u(style, canon3, ub);
-  if ((rc = bp_point_mul(ctx, ub, g.gen_h, 1, u)) != BP_OK) return rc;
+  if ((rc = point_mul_gen(ctx, w, g, ub, u)) != BP_OK) return rc;
 
   // verifyTPoly (:43-54): commit t tBlinding == gen*gExp + sumExps xs tCommits + sumExps vExp vCommits,
   // evaluated as one multiexp of the difference, which is O exactly when both sides are equal.
