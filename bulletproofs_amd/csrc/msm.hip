@@ -27,7 +27,8 @@ constexpr int SLICE = 2048;          // entries per heavy slice (one 256-thread 
 
 // ---- 1. digits + histogram --------------------------------------------------
 __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars, uint32_t n, MsmPlan pl,
-                                               uint32_t* __restrict__ codes, uint32_t* __restrict__ hist) {
+                                               uint32_t* __restrict__ codes, uint32_t* __restrict__ ranks,
+                                               uint32_t* __restrict__ hist) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u256 s = ld_u256(scalars + (size_t)i * 32);
@@ -35,8 +36,71 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scal
   for (int w = 0; w < pl.W; w++) {
     uint32_t code = recode_next(s, pl.c, carry);
     codes[(size_t)w * n + i] = code;
-    if (code != MSM_SKIP) atomicAdd(&hist[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
+    // the histogram increment also hands this entry its rank inside the bucket, so the scatter pass
+    // needs no second round of atomics
+    if (code != MSM_SKIP) ranks[(size_t)w * n + i] = atomicAdd(&hist[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
   }
+}
+
+// GLV form (glv.h): scalar i becomes the two 129-bit half-scalars k1, k2 with k = k1 + k2*lambda; entry 2i is
+// k1 on P_i, entry 2i + 1 is k2 on phi(P_i) = (beta x, y).  Half the windows, hence half the buckets to
+// reduce and half the doublings in the final Horner chain; a half-scalar's sign flips the entry's sign flag.
+__global__ void __launch_bounds__(256) k_recode_glv(const uint8_t* __restrict__ scalars, uint32_t n, MsmPlan pl,
+                                                   uint32_t* __restrict__ codes, uint32_t* __restrict__ ranks,
+                                                   uint32_t* __restrict__ hist) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)i * 32));
+  GlvHalf h[2];
+  glv_split(k, h[0], h[1]);
+  const size_t ne = (size_t)2 * n;
+  const int top_bits = GLV_BITS + 1 - pl.c * (pl.W - 1);
+#pragma unroll
+  for (int hh = 0; hh < 2; hh++) {
+    u256 s = u256_zero();
+#pragma unroll
+    for (int q = 0; q < 5; q++) s.v[q] = h[hh].m[q];
+    const uint32_t flip = h[hh].neg ? MSM_NEG : 0u;
+    const size_t j = (size_t)2 * i + hh;
+    uint32_t carry = 0;
+    for (int w = 0; w < pl.W; w++) {
+      uint32_t code = recode_next(s, pl.c, carry);
+      if (code != MSM_SKIP) code ^= flip;
+      codes[(size_t)w * ne + j] = code;
+      if (w == pl.W - 1 && top_bits <= 5) break;  // handled below, wave-aggregated
+      if (code != MSM_SKIP) ranks[(size_t)w * ne + j] = atomicAdd(&hist[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
+    }
+  }
+}
+
+// The top window of the GLV form holds only the last few bits (2 for c = 16): a million entries would
+// hammer a handful of counters.  Ranks come from LDS counters per workgroup plus one global atomic per
+// workgroup and distinct bucket (at most 32 buckets: top_bits <= 5).
+__global__ void __launch_bounds__(256) k_rank_top(uint32_t ne, MsmPlan pl, const uint32_t* __restrict__ codes,
+                                                 uint32_t* __restrict__ ranks, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t cnt[32], base[32];
+  if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = pl.W - 1;
+  uint32_t code = j < ne ? codes[(size_t)w * ne + j] : MSM_SKIP;
+  bool valid = code != MSM_SKIP;
+  uint32_t bucket = (code & ~MSM_NEG) & 31u;
+  uint32_t local = 0;
+  if (valid) local = atomicAdd(&cnt[bucket], 1u);
+  __syncthreads();
+  if (threadIdx.x < 32 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[(size_t)w * pl.nb + threadIdx.x], cnt[threadIdx.x]);
+  __syncthreads();
+  if (valid) ranks[(size_t)w * ne + j] = base[bucket] + local;
+}
+
+// point of a sorted entry: plain index, or (index >> 1, endomorphism flag) in GLV form
+__device__ __forceinline__ affine entry_point(const uint8_t* __restrict__ points, uint32_t e, uint32_t glv) {
+  uint32_t idx = e & ~MSM_NEG;
+  if (!glv) return ld_affine(points + (size_t)idx * 64);
+  affine p = ld_affine(points + (size_t)(idx >> 1) * 64);
+  if (idx & 1u) p = glv_phi(p);
+  return p;
 }
 
 // ---- 2. per-window exclusive scan (one workgroup of 1024 per window) -----------
@@ -71,14 +135,15 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
 }
 
 // ---- 3. scatter ------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ codes, uint32_t n, MsmPlan pl,
-                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ ranks,
+                                                uint32_t n, MsmPlan pl, const uint32_t* __restrict__ offs,
+                                                uint32_t* __restrict__ sorted) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   int w = blockIdx.y;
   if (i >= n) return;
   uint32_t code = codes[(size_t)w * n + i];
   if (code == MSM_SKIP) return;
-  uint32_t pos = atomicAdd(&cursor[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
+  uint32_t pos = offs[(size_t)w * pl.nb + (code & ~MSM_NEG)] + ranks[(size_t)w * n + i];
   sorted[pos] = i | (code & MSM_NEG);
 }
 
@@ -130,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_cls_scatter(const uint32_t* __restrict
 // ---- 5a. light buckets: one lane per bucket ----------------------------------------
 __global__ void __launch_bounds__(256) k_light(const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
                                               const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
-                                              const uint32_t* __restrict__ order, uint32_t total,
+                                              const uint32_t* __restrict__ order, uint32_t total, uint32_t glv,
                                               xyzz* __restrict__ buckets) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
@@ -141,13 +206,13 @@ __global__ void __launch_bounds__(256) k_light(const uint8_t* __restrict__ point
   if (cnt) {
     const uint32_t* lst = sorted + offs[bid];
     uint32_t e = lst[0];
-    affine p = ld_affine(points + (size_t)(e & ~MSM_NEG) * 64);
+    affine p = entry_point(points, e, glv);
     for (uint32_t k = 0; k < cnt; k++) {
       affine cur = p;
       uint32_t ecur = e;
       if (k + 1 < cnt) {  // prefetch the next point behind the arithmetic
         e = lst[k + 1];
-        p = ld_affine(points + (size_t)(e & ~MSM_NEG) * 64);
+        p = entry_point(points, e, glv);
       }
       bucket_add(acc, cur, (ecur & MSM_NEG) != 0);
     }
@@ -193,7 +258,7 @@ __global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict_
                                                      const uint32_t* __restrict__ sorted,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ bins,
-                                                     const uint32_t* __restrict__ heavy_off,
+                                                     const uint32_t* __restrict__ heavy_off, uint32_t glv,
                                                      xyzz* __restrict__ partial) {
   __shared__ xyzz lds[4];
   uint32_t nheavy = bins[2 * NBINS];
@@ -214,7 +279,7 @@ __global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict_
     xyzz acc = xyzz_inf();
     for (uint32_t k = s0 + threadIdx.x; k < s1; k += blockDim.x) {
       uint32_t e = lst[k];
-      affine p = ld_affine(points + (size_t)(e & ~MSM_NEG) * 64);
+      affine p = entry_point(points, e, glv);
       bucket_add(acc, p, (e & MSM_NEG) != 0);
     }
     acc = block_sum(acc, lds);
@@ -404,8 +469,10 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
     ctx->err = "bp_msm: window_bits must be in 1..16";
     return BP_ERR_ARG;
   }
-  MsmPlan pl = msm_plan(c);
-  size_t wn = (size_t)pl.W * n;
+  static const uint32_t glv = getenv("BP_MSM_NO_GLV") ? 0u : 1u;
+  MsmPlan pl = msm_plan(c, glv ? GLV_BITS : 256);
+  const size_t ne = glv ? 2 * n : n;  // sorted entries per window
+  size_t wn = (size_t)pl.W * ne;
   if (wn >= (1ull << 32)) {
     ctx->err = "bp_msm: windows * n must be below 2^32";
     return BP_ERR_ARG;
@@ -415,7 +482,7 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   size_t max_slices = wn / SLICE + max_heavy + 1;
 
   // workspace layout (sizes computed with a null base first)
-  uint32_t *codes, *sorted, *hist, *offs, *cursor, *order, *bins, *heavy_off;
+  uint32_t *codes, *ranks, *sorted, *hist, *offs, *cursor, *order, *bins, *heavy_off;
   xyzz *partial, *buckets, *segv, *wsum;
   auto carve = [&](void* base) {
     Carver cv(base);
@@ -423,6 +490,7 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
     bins = cv.take<uint32_t>(2 * NBINS + 8); // zeroed each call (contiguous with hist)
     size_t zero_end = cv.off;
     codes = cv.take<uint32_t>(wn);
+    ranks = cv.take<uint32_t>(wn);
     sorted = cv.take<uint32_t>(wn);
     offs = cv.take<uint32_t>(nbt);
     cursor = cv.take<uint32_t>(nbt);
@@ -444,11 +512,18 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   size_t zero_bytes = (size_t)((char*)(bins + 2 * NBINS + 8) - (char*)hist);
   BP_TRY(hipMemsetAsync(hist, 0, zero_bytes, st));
 
-  uint32_t n32 = (uint32_t)n, nbt32 = (uint32_t)nbt;
-  hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl, codes,
-                     hist);
-  hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, n32, pl, offs, cursor);
-  hipLaunchKernelGGL(k_scatter, dim3((n32 + 255) / 256, pl.W), dim3(256), 0, st, codes, n32, pl, cursor, sorted);
+  uint32_t n32 = (uint32_t)n, ne32 = (uint32_t)ne, nbt32 = (uint32_t)nbt;
+  if (glv)
+    hipLaunchKernelGGL(k_recode_glv, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl,
+                       codes, ranks, hist);
+  if (glv && GLV_BITS + 1 - pl.c * (pl.W - 1) <= 5)
+    hipLaunchKernelGGL(k_rank_top, dim3((ne32 + 255) / 256), dim3(256), 0, st, ne32, pl, codes, ranks, hist);
+  if (glv) {
+  } else
+    hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl, codes,
+                       ranks, hist);
+  hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, ne32, pl, offs, cursor);
+  hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W), dim3(256), 0, st, codes, ranks, ne32, pl, offs, sorted);
   hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
   hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
   hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
@@ -467,7 +542,7 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
     BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
   }
   hipLaunchKernelGGL(k_light, dim3((nbt32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs,
-                     sorted, order, nbt32, buckets);
+                     sorted, order, nbt32, glv, buckets);
   if (ctx->profile) {
     BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
     ctx->prof_pending_light = true;
@@ -476,7 +551,7 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
   uint32_t hgrid = (uint32_t)(max_slices < 4096 ? max_slices : 4096);
   hipLaunchKernelGGL(k_heavy_slices, dim3(hgrid), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,
-                     order, bins, heavy_off, partial);
+                     order, bins, heavy_off, glv, partial);
   uint32_t fgrid = (uint32_t)(max_heavy < 4096 ? max_heavy : 4096);
   hipLaunchKernelGGL(k_heavy_final, dim3(fgrid), dim3(64), 0, st, order, bins, heavy_off, partial, buckets);
   uint32_t nsegt = (uint32_t)pl.W * pl.nseg;

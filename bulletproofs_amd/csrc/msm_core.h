@@ -22,12 +22,17 @@ struct MsmPlan {
   int nseg;      // segments per window = nb / seg
 };
 
-BP_HD MsmPlan msm_plan(int c) {
+// `bits`: width of the scalars fed to the recoder (256 for plain scalars, 129 for GLV half-scalars);
+// one more bit is kept for the carry of the signed recoding.
+#ifndef MSM_SEG
+#define MSM_SEG 8
+#endif
+BP_HD MsmPlan msm_plan(int c, int bits = 256) {
   MsmPlan p;
   p.c = c;
-  p.W = (257 + c - 1) / c;
+  p.W = (bits + 1 + c - 1) / c;
   p.nb = 1 << (c - 1);
-  p.seg = p.nb < 32 ? p.nb : 32;
+  p.seg = p.nb < MSM_SEG ? p.nb : MSM_SEG;
   p.nseg = p.nb / p.seg;
   return p;
 }
