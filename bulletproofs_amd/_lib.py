@@ -77,6 +77,10 @@ SYMBOLS = {
     "bp_ipp_prove": (_int, [_vp, ctypes.c_uint32] + [_u8p] * 10),
     "bp_upper_bound_bits": (_int, [_u8p, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "bp_rangeproof_prove": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32] + [_u8p] * 8 + [_int, _u8p, _u8p]),
+    "bp_rangeproof_wire_size": (_sz, [ctypes.c_uint32]),
+    "bp_rangeproof_serialize": (_int, [_u8p, _u8p, ctypes.c_uint32, _u8p, _sz, ctypes.POINTER(_sz)]),
+    "bp_rangeproof_deserialize": (_int, [_u8p, _sz, ctypes.POINTER(ctypes.c_uint32), _u8p, _u8p, _sz]),
+    "bp_rangeproof_show": (_int, [_u8p, _u8p, ctypes.c_uint32, _int, _u8p, _sz, ctypes.POINTER(_sz)]),
     "bp_ac_proof_points": (_int, [ctypes.c_uint32]),
     "bp_ac_prove": (_int, [_vp] + [ctypes.c_uint32] * 3 + [_u8p] * 14),
     "bp_ac_verify": (_int, [_vp] + [ctypes.c_uint32] * 3 + [_u8p] * 9),
@@ -376,6 +380,57 @@ def transcript(style, which, pts=(), scs=(), raw=b""):
     if rc != 0:
         raise BpError("bp_transcript failed: %d" % rc)
     return dec_scalar(out.raw)
+
+
+def _proof_arrays(proof):
+    ipp = proof["productProof"]
+    sc = enc_scalars([proof["tBlinding"], proof["mu"], proof["t"], ipp["l"], ipp["r"]])
+    pts = enc_points([proof["aCommit"], proof["sCommit"], proof["t1Commit"], proof["t2Commit"]]
+                     + list(ipp["lCommits"]) + list(ipp["rCommits"]))
+    return sc, pts, len(ipp["lCommits"])
+
+
+def serialize_proof(proof):
+    """Range proof (the oracle's dict) -> canonical bytes (bp_rangeproof_serialize)."""
+    lib = load_library()
+    sc, pts, k = _proof_arrays(proof)
+    cap = lib.bp_rangeproof_wire_size(k)
+    out = ctypes.create_string_buffer(cap)
+    n = _sz()
+    rc = lib.bp_rangeproof_serialize(sc, pts, k, out, cap, ctypes.byref(n))
+    if rc != 0:
+        raise BpError("bp_rangeproof_serialize failed: %d" % rc)
+    return out.raw[:n.value]
+
+
+def deserialize_proof(data):
+    """Canonical bytes -> range proof dict; raises BpError on any malformed input."""
+    lib = load_library()
+    k = ctypes.c_uint32()
+    sc = ctypes.create_string_buffer(5 * 32)
+    cap = 4 + 2 * 255
+    pts = ctypes.create_string_buffer(cap * 64)
+    rc = lib.bp_rangeproof_deserialize(bytes(data), len(data), ctypes.byref(k), sc, pts, cap)
+    if rc != 0:
+        raise BpError("bp_rangeproof_deserialize failed: %d" % rc)
+    kk = k.value
+    s = dec_scalars(sc.raw, 5)
+    p = dec_points(pts.raw, 4 + 2 * kk)
+    return dict(tBlinding=s[0], mu=s[1], t=s[2], aCommit=p[0], sCommit=p[1], t1Commit=p[2], t2Commit=p[3],
+                productProof=dict(lCommits=p[4:4 + kk], rCommits=p[4 + kk:4 + 2 * kk], l=s[3], r=s[4]))
+
+
+def show_proof(proof, style=0):
+    """`show proof` as GHC derives it for RangeProof Fr PA."""
+    lib = load_library()
+    sc, pts, k = _proof_arrays(proof)
+    cap = 1024 + (4 + 2 * k) * 192
+    out = ctypes.create_string_buffer(cap)
+    n = _sz()
+    rc = lib.bp_rangeproof_show(sc, pts, k, style, out, cap, ctypes.byref(n))
+    if rc != 0:
+        raise BpError("bp_rangeproof_show failed: %d" % rc)
+    return out.raw[:n.value]
 
 
 def upper_bound_bits(upper_bound):

@@ -245,6 +245,27 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
                  const uint8_t* wO, const uint8_t* wV, const uint8_t* cs, const uint8_t* v_commits,
                  const uint8_t* proof_scalars, const uint8_t* proof_points, uint8_t* verdict);
 
+/* ---- canonical proof bytes and `show` text (host only) ----
+ * The reference defines no serialisation (its records derive Show/Eq/Generic/NFData only,
+ * RangeProof/Internal.hs:14-38, InnerProductProof/Internal.hs:10-24); this layout is this library's:
+ *   tBlinding | mu | t | aCommit | sCommit | t1Commit | t2Commit | k | L_1..L_k | R_1..R_k | l | r
+ * scalars 32 B big-endian canonical; points 0x04|x|y (big-endian, canonical, on the curve) or 0x00 for O;
+ * k one byte.  In memory: scalars 5 x 32 B little-endian (tBlinding, mu, t, l, r), points (4 + 2k) x 64 B as
+ * bp_rangeproof_prove returns them.
+ * bp_rangeproof_wire_size   upper bound of the encoded size for k rounds.
+ * bp_rangeproof_serialize / _deserialize   strict: non-canonical values, off-curve points, unknown tags,
+ *                   truncation and trailing bytes are BP_ERR_ARG.
+ * bp_rangeproof_show   the text GHC's derived Show gives for `RangeProof Fr PA` (record syntax), with the
+ *                   element format of bp_ctx_set_show_style: for eyeball diffs against a GHC run.
+ */
+size_t bp_rangeproof_wire_size(uint32_t k);
+int bp_rangeproof_serialize(const uint8_t* scalars, const uint8_t* points, uint32_t k, uint8_t* out, size_t cap,
+                            size_t* len);
+int bp_rangeproof_deserialize(const uint8_t* in, size_t len, uint32_t* k, uint8_t* scalars, uint8_t* points,
+                              size_t points_cap);
+int bp_rangeproof_show(const uint8_t* scalars, const uint8_t* points, uint32_t k, int style, char* out, size_t cap,
+                       size_t* len);
+
 /* ---- field arithmetic self-test hooks (used by the parity tests) ----
  * op: 0 add, 1 sub, 2 mul, 3 square(a), 4 inverse(a), 5 negate(a),
  *     6 a^((p+1)/4), the square-root candidate `sr` uses (field 0 only; Utils.hs:47)

@@ -854,3 +854,34 @@ def ac_draw_blinders(rng, n):
     s_r = [rng.randint(1, 2**n - 1) % R for _ in range(n)] if n else []
     five = [rng.randint(1, R - 1) for _ in range(5)]
     return (*three, s_l, s_r, five)
+
+
+# --------------------------------------------------------------------------
+# Proof bytes and `show` text.  NOT part of the reference (it has no serialisation, only derived
+# Show/Eq/Generic/NFData: RangeProof/Internal.hs:38, InnerProductProof/Internal.hs:24); this is the
+# independent restatement of the layout documented in include/bpgpu.h, used to cross-check
+# bp_rangeproof_serialize / _deserialize / _show.
+# --------------------------------------------------------------------------
+def wire_point(pt):
+    return b"\x00" if pt is O else b"\x04" + pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big")
+
+
+def wire_encode(proof):
+    ipp = proof["productProof"]
+    out = b"".join(proof[k].to_bytes(32, "big") for k in ("tBlinding", "mu", "t"))
+    out += b"".join(wire_point(proof[k]) for k in ("aCommit", "sCommit", "t1Commit", "t2Commit"))
+    out += bytes([len(ipp["lCommits"])])
+    out += b"".join(wire_point(p) for p in ipp["lCommits"]) + b"".join(wire_point(p) for p in ipp["rCommits"])
+    return out + ipp["l"].to_bytes(32, "big") + ipp["r"].to_bytes(32, "big")
+
+
+def show_range_proof(proof):
+    """Derived `Show` of the record types (record syntax, declaration order of the fields)."""
+    ipp = proof["productProof"]
+    lst = lambda ps: b"[" + b",".join(show_point(p) for p in ps) + b"]"
+    return (b"RangeProof {tBlinding = " + show_fr(proof["tBlinding"]) + b", mu = " + show_fr(proof["mu"])
+            + b", t = " + show_fr(proof["t"]) + b", aCommit = " + show_point(proof["aCommit"])
+            + b", sCommit = " + show_point(proof["sCommit"]) + b", t1Commit = " + show_point(proof["t1Commit"])
+            + b", t2Commit = " + show_point(proof["t2Commit"])
+            + b", productProof = InnerProductProof {lCommits = " + lst(ipp["lCommits"]) + b", rCommits = "
+            + lst(ipp["rCommits"]) + b", l = " + show_fr(ipp["l"]) + b", r = " + show_fr(ipp["r"]) + b"}}")

@@ -93,6 +93,64 @@ def main():
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote vectors.json")
+    circuit_vectors()
+
+
+def ac_proof_json(pr):
+    ipp = pr["productProof"]
+    return dict(tBlinding=hx(pr["tBlinding"]), mu=hx(pr["mu"]), t=hx(pr["t"]), aiCommit=hp(pr["aiCommit"]),
+                aoCommit=hp(pr["aoCommit"]), sCommit=hp(pr["sCommit"]), tCommits=[hp(p) for p in pr["tCommits"]],
+                lCommits=[hp(p) for p in ipp["lCommits"]], rCommits=[hp(p) for p in ipp["rCommits"]],
+                l=hx(ipp["l"]), r=hx(ipp["r"]))
+
+
+def circuit_vectors():
+    """Arithmetic-circuit fixtures: the fixed circuits of the reference's own suite
+    (test/Test/Protocol/ArithCircuit.hs:48-83 Hadamard with n = 4 here, :167-207 shuffle) with seeded
+    witnesses and blinders; written to circuit_vectors.json (vectors.json stays untouched)."""
+    R = o.R
+    rng = random.Random(50)
+    out = {}
+
+    def record(name, circuit, witness, n2):
+        bl = o.ac_draw_blinders(rng, n2)
+        pr = o.ac_generate_proof(circuit, witness, *bl)
+        assert o.ac_verify_proof(witness["commitments"], pr, circuit)
+        fx = lambda rows: [[hx(v % R) for v in row] for row in rows]
+        out[name] = dict(
+            circuit=dict(wL=fx(circuit["wL"]), wR=fx(circuit["wR"]), wO=fx(circuit["wO"]),
+                         commitmentWeights=fx(circuit["commitmentWeights"]), cs=[hx(v % R) for v in circuit["cs"]]),
+            assignment={k: [hx(v % R) for v in witness["assignment"][k]] for k in ("aL", "aR", "aO")},
+            commitBlinders=[hx(v) for v in witness["commitBlinders"]],
+            commitments=[hp(p) for p in witness["commitments"]],
+            blinders=dict(aiBlinding=hx(bl[0]), aoBlinding=hx(bl[1]), sBlinding=hx(bl[2]), sL=[hx(v) for v in bl[3]],
+                          sR=[hx(v) for v in bl[4]], tBlindings=[hx(v) for v in bl[5]]),
+            proof=ac_proof_json(pr), verifies=True)
+
+    n = 4
+    a_l = [rng.randrange(R) for _ in range(n)]
+    a_r = [rng.randrange(R) for _ in range(n)]
+    r, s2 = rng.randrange(R), rng.randrange(R)
+    circuit = dict(wL=[[1] * n, [0] * n], wR=[[0] * n, [1] * n], wO=[[0] * n, [0] * n],
+                   commitmentWeights=[[1, 0], [0, 1]], cs=[0, 0])
+    witness = dict(assignment=dict(aL=a_l, aR=a_r, aO=o.hadamard(a_l, a_r)),
+                   commitments=[o.commit(sum(a_l) % R, r), o.commit(sum(a_r) % R, s2)], commitBlinders=[r, s2])
+    record("hadamard4", circuit, witness, 4)
+
+    z = rng.randrange(R)
+    circuit = dict(wL=[[0, 0], [1, 0], [0, 1], [0, 0], [0, 0]], wR=[[0, 0], [0, 0], [0, 0], [1, 0], [0, 1]],
+                   wO=[[1, -1], [0, 0], [0, 0], [0, 0], [0, 0]],
+                   commitmentWeights=[[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]],
+                   cs=[0, -z, -z, -z, -z])
+    a_l = [(4 - z) % R, (9 - z) % R]
+    a_r = [(9 - z) % R, (4 - z) % R]
+    bl = [rng.randrange(R) for _ in range(4)]
+    witness = dict(assignment=dict(aL=a_l, aR=a_r, aO=o.hadamard(a_l, a_r)),
+                   commitments=[o.commit(v, b) for v, b in zip([4, 9, 9, 4], bl)], commitBlinders=bl)
+    record("shuffle", circuit, witness, 2)
+    with open(os.path.join(HERE, "circuit_vectors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote circuit_vectors.json")
 
 
 if __name__ == "__main__":

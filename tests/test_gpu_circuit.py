@@ -181,3 +181,13 @@ def test_config5_shape_round_trip(engine):
     assert engine.ac_verify(commitments, dict(proof, t=(proof["t"] + 1) % R), circuit) is False
     assert engine.ac_verify([commitments[1], commitments[0]], proof, circuit) is False
     engine.set_generators(o.gs(128), o.hs(128), o.h())
+
+
+def test_golden_circuit_proofs(eng_gens):
+    """The committed fixtures (tests/golden/circuit_vectors.json): engine proof == fixture, verdicts agree."""
+    from util import circuit_golden, load_circuit_case
+    for name, c in circuit_golden().items():
+        circuit, witness, blinders, proof = load_circuit_case(c)
+        assert eng_gens.ac_prove(circuit, witness, *blinders) == proof, name
+        assert eng_gens.ac_verify(witness["commitments"], proof, circuit) is True
+        assert eng_gens.ac_verify(witness["commitments"], dict(proof, mu=(proof["mu"] + 1) % R), circuit) is False

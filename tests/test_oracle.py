@@ -235,3 +235,32 @@ def test_ipp_standalone():
 def test_log_base2_matches_double_arithmetic():
     assert all(o.log_base2(2**k) == k for k in range(1, 257))
     assert o.log_base2(2**64 + 1) == 64 and o.log_base2(2**64 - 1) == 64  # Double rounding, as in Haskell
+
+
+# ---- arithmetic circuits (ArithmeticCircuit/*.hs) ----------------------------------------------
+def test_golden_circuit_proofs():
+    from util import circuit_golden, load_circuit_case
+    for name, c in circuit_golden().items():
+        circuit, witness, blinders, proof = load_circuit_case(c)
+        assert o.ac_generate_proof(circuit, witness, *blinders) == proof, name
+        assert o.ac_verify_proof(witness["commitments"], proof, circuit) is True
+        assert o.ac_verify_proof(witness["commitments"], dict(proof, mu=(proof["mu"] + 1) % o.R), circuit) is False
+
+
+def test_circuit_completeness_on_reference_circuits():
+    """test/Test/Protocol/ArithCircuit.hs: n = 0 / m = 3 (:92-117) and n = 1 / m = 0 (:130-153)."""
+    rng = random.Random(77)
+    bl = [rng.randrange(o.R) for _ in range(3)]
+    circuit = dict(wL=[[]], wR=[[]], wO=[[]], commitmentWeights=[[1, 1, -1]], cs=[0])
+    witness = dict(assignment=dict(aL=[], aR=[], aO=[]), commitments=[o.commit(v, b) for v, b in zip([2, 5, 7], bl)],
+                   commitBlinders=bl)
+    pr = o.ac_generate_proof(circuit, witness, *o.ac_draw_blinders(rng, 0))
+    assert o.ac_verify_proof(witness["commitments"], pr, circuit)
+    bad = [o.commit(3, bl[0])] + witness["commitments"][1:]
+    assert not o.ac_verify_proof(bad, pr, circuit)
+    circuit = dict(wL=[[0], [0], [1]], wR=[[0], [1], [0]], wO=[[1], [0], [0]], commitmentWeights=[[], [], []],
+                   cs=[35, 5, 7])
+    witness = dict(assignment=dict(aL=[7], aR=[5], aO=[35]), commitments=[], commitBlinders=[])
+    pr = o.ac_generate_proof(circuit, witness, *o.ac_draw_blinders(rng, 1))
+    assert o.ac_verify_proof([], pr, circuit)
+    assert not o.ac_verify_proof([], pr, dict(circuit, cs=[36, 5, 7]))
