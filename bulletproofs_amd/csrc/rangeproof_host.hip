@@ -243,11 +243,9 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
   auto t_entry = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
 #define TRACE(what, c, r, t0) do { if (trace) fprintf(stderr, "[vjob] %-8s chunk %d round %d  %8.3f -> %8.3f ms\n", what, (int)(c), (int)(r), t0, now_ms()); } while (0)
-  int cidx = 0;
   // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
-  for (auto& ch : job->chunks) {
+  auto hash0 = [&](Chunk& ch) {
     const size_t B = ch.B;
-    double t_h = now_ms();
     job->pool->run(
         [&](size_t a, size_t b) {
           uint8_t buf[MSG_SCRATCH];
@@ -292,48 +290,74 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
           }
         },
         B);
-    TRACE("hash0", cidx, -1, t_h);
-    cidx++;
-    if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc)) != BP_OK) return rc;
-  }
-  // mkChallenges (InnerProductProof/Verifier.hs:44-53)
-  for (uint32_t r = 0; r < k; r++) {
-    cidx = 0;
-    for (auto& ch : job->chunks) {
-      const size_t B = ch.B;
-      double t_w = now_ms();
-      if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
-      TRACE("wait", cidx, r, t_w);
-      double t_h = now_ms();
-      job->pool->run(
-          [&](size_t a, size_t b) {
-            uint8_t buf[MSG_SCRATCH];
-            for (size_t p = a; p < b; p++) {
-              // shamirX' acc L R = oracle (show _r <> L <> R <> acc)   (Utils.hs:167-170)
-              Msg mm(buf, st);
-              mm.r();
-              mm.point(ch.pts + ((size_t)(VP_L0 + r) * B + p) * 64);
-              mm.point(ch.pts + ((size_t)(VP_L0 + k + r) * B + p) * 64);
-              mm.point(ch.acc + p * 64);
-              mm.finish_fr(ch.xk + p * 32);
-            }
-          },
-          B);
-      TRACE("hashR", cidx, r, t_h);
-      cidx++;
-      if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc)) != BP_OK) return rc;
+  };
+  // mkChallenges (InnerProductProof/Verifier.hs:44-53): shamirX' acc L R = oracle (show _r <> L <> R <> acc)
+  auto hashR = [&](Chunk& ch, uint32_t r) {
+    const size_t B = ch.B;
+    job->pool->run(
+        [&](size_t a, size_t b) {
+          uint8_t buf[MSG_SCRATCH];
+          for (size_t p = a; p < b; p++) {
+            Msg mm(buf, st);
+            mm.r();
+            mm.point(ch.pts + ((size_t)(VP_L0 + r) * B + p) * 64);
+            mm.point(ch.pts + ((size_t)(VP_L0 + k + r) * B + p) * 64);
+            mm.point(ch.acc + p * 64);
+            mm.finish_fr(ch.xk + p * 32);
+          }
+        },
+        B);
+  };
+  // Every chunk walks the stages 0 (hash y,z,x,u -> begin), 1..k (hash x_r -> round r-1), k+1 (-> finish),
+  // k+2 (verdicts in).  The host always serves the READY chunk that is furthest along, so the chunks
+  // spread out in time: while the host hashes later chunks the GPU already runs the final multiexp of
+  // earlier ones, and nothing waits for a whole round to finish across chunks.
+  const size_t nc = job->chunks.size();
+  std::vector<uint32_t> stage(nc, 0);
+  size_t finished = 0;
+  while (finished < nc) {
+    int pick = -1;
+    for (size_t c = 0; c < nc; c++) {
+      if (stage[c] > k + 1) continue;  // verdicts pending or done
+      if (stage[c] > 0 && !vbatch_ready(job->chunks[c].vb)) continue;
+      if (pick < 0 || stage[c] > stage[pick]) pick = (int)c;
     }
+    if (pick < 0) {
+      // nothing to hash right now: collect a chunk whose verdicts are in, else poll until some chunk's
+      // GPU work completes (blocking on one particular stream could sit out a 6 ms final phase while a
+      // 2 ms round of another chunk finishes)
+      bool collected = false;
+      for (size_t c = 0; c < nc; c++)
+        if (stage[c] == k + 2 && vbatch_ready(job->chunks[c].vb)) {
+          Chunk& ch = job->chunks[c];
+          if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
+          memcpy(verdicts + ch.first, ch.verdict, ch.B);
+          stage[c] = k + 3;
+          finished++;
+          collected = true;
+        }
+      if (!collected) std::this_thread::yield();
+      continue;
+    }
+    Chunk& ch = job->chunks[pick];
+    double t_h = now_ms();
+    if (stage[pick] == 0) {
+      hash0(ch);
+      TRACE("hash0", pick, -1, t_h);
+      if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc)) != BP_OK) return rc;
+    } else if (stage[pick] <= k) {
+      if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;  // completed already: folds the profiling events in
+      uint32_t r = stage[pick] - 1;
+      hashR(ch, r);
+      TRACE("hashR", pick, r, t_h);
+      if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc)) != BP_OK) return rc;
+    } else {
+      if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
+      if ((rc = vbatch_finish_async(ch.vb, ch.verdict)) != BP_OK) return rc;
+      TRACE("finish", pick, -1, t_h);
+    }
+    stage[pick]++;
   }
-  double t_f = now_ms();
-  for (auto& ch : job->chunks) {
-    if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
-    if ((rc = vbatch_finish_async(ch.vb, ch.verdict)) != BP_OK) return rc;
-  }
-  for (auto& ch : job->chunks) {
-    if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
-    memcpy(verdicts + ch.first, ch.verdict, ch.B);
-  }
-  TRACE("final", -1, -1, t_f);
 #undef TRACE
   return BP_OK;
 }

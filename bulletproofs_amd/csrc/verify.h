@@ -55,6 +55,7 @@ struct bp_vbatch {
   bool direct_host;
   // profiling: event pairs around the three k_fixed_multiexp launches
   hipEvent_t ev[3][2];
+  hipEvent_t done;  // recorded behind the last command of each *_async call (vbatch_ready)
   bool ev_pending[3];
   double ev_madds[3];
 };
@@ -67,4 +68,6 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
 int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
 int vbatch_wait(bp_vbatch* vb);
+// has everything enqueued by the last *_async call completed?  (non-blocking)
+bool vbatch_ready(bp_vbatch* vb);
 }  // namespace bp

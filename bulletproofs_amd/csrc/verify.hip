@@ -456,6 +456,10 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
   return BP_OK;
 }
 
+// A stream query, not an event: recording an event behind the kernels puts a marker packet into the queue,
+// and such packets were measured to break the overlap between chunk streams just like copy commands do.
+bool vbatch_ready(bp_vbatch* vb) { return hipStreamQuery(vb->stream) == hipSuccess; }
+
 int vbatch_wait(bp_vbatch* vb) {
   bp_ctx* ctx = vb->ctx;
   BP_TRY(hipStreamSynchronize(vb->stream));
@@ -535,6 +539,8 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   size_t need = carve(nullptr);
   vb->stream = ctx_chunk_stream(ctx);  // from the context's concurrent set; not owned
   hipError_t e = hipSuccess;
+  vb->done = nullptr;
+  e = hipEventCreateWithFlags(&vb->done, hipEventDisableTiming);
   for (int s2 = 0; s2 < 3; s2++) {
     vb->ev_pending[s2] = false;
     vb->ev[s2][0] = vb->ev[s2][1] = nullptr;
@@ -585,6 +591,7 @@ void bp_vbatch_destroy(bp_vbatch* vb) {
   for (int s = 0; s < 3; s++)
     for (int j = 0; j < 2; j++)
       if (vb->ev[s][j]) (void)hipEventDestroy(vb->ev[s][j]);
+  if (vb->done) (void)hipEventDestroy(vb->done);
   delete vb;
 }
 
