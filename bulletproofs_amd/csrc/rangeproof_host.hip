@@ -243,6 +243,7 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
   auto t_entry = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
 #define TRACE(what, c, r, t0) do { if (trace) fprintf(stderr, "[vjob] %-8s chunk %d round %d  %8.3f -> %8.3f ms\n", what, (int)(c), (int)(r), t0, now_ms()); } while (0)
+  const ShaMid r_mid = sha_mid_show_r();  // every transcript opens with the first block of `show _r`
   // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
   auto hash0 = [&](Chunk& ch) {
     const size_t B = ch.B;
@@ -263,30 +264,32 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
             my.r();
             my.point(A);
             my.point(S);
-            size_t as_len = my.len;  // the text of show _r <> A <> S is shared by all three
-            uint8_t keep[MSG_SCRATCH];
-            memcpy(keep, buf, as_len);
-            my.finish_fr(y);
+            // the text of show _r <> A <> S opens all three messages: its full SHA blocks are absorbed once,
+            // and it stays in place in `buf` (padding is only ever written behind it)
+            const size_t as_len = my.len;
+            ShaMid mid = r_mid;
+            sha_mid_advance(mid, buf, as_len);
+            my.finish_fr_from(mid, y);
             // shamirZ: ... <> show y   (Utils.hs:150-153)
             Msg mz(buf, st);
-            mz.raw(keep, as_len);
+            mz.len = as_len;
             mz.fr(y);
-            mz.finish_fr(z);
+            mz.finish_fr_from(mid, z);
             // shamirX: show _r <> A <> S <> T1 <> T2 <> show y <> show z   (Utils.hs:155-165)
             Msg mx(buf, st);
-            mx.raw(keep, as_len);
+            mx.len = as_len;
             mx.point(T1);
             mx.point(T2);
             mx.fr(y);
             mx.fr(z);
-            mx.finish_fr(x);
+            mx.finish_fr_from(mid, x);
             // shamirU: show _r <> show tBlinding <> show mu <> show t   (Utils.hs:172-174)
             Msg mu(buf, st);
             mu.r();
             mu.fr(ch.sc + ((size_t)VS_TAU * B + p) * 32);
             mu.fr(ch.sc + ((size_t)VS_MU * B + p) * 32);
             mu.fr(ch.sc + ((size_t)VS_T * B + p) * 32);
-            mu.finish_fr(u);
+            mu.finish_fr_from(r_mid, u);
           }
         },
         B);
@@ -303,7 +306,7 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
             mm.point(ch.pts + ((size_t)(VP_L0 + r) * B + p) * 64);
             mm.point(ch.pts + ((size_t)(VP_L0 + k + r) * B + p) * 64);
             mm.point(ch.acc + p * 64);
-            mm.finish_fr(ch.xk + p * 32);
+            mm.finish_fr_from(r_mid, ch.xk + p * 32);
           }
         },
         B);

@@ -152,6 +152,41 @@ static inline void sha256_inplace(uint8_t* msg, size_t len, uint8_t out[32]) {
   }
 }
 
+// SHA-256 state after the first `done` bytes (a multiple of 64) of a message: transcripts that share a
+// prefix (every message starts with `show _r`; shamirY/Z/X share `show _r <> A <> S`) hash it once
+struct ShaMid {
+  uint32_t st[8];
+  size_t done;
+};
+static inline ShaMid sha_mid_init() {
+  return ShaMid{{0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}, 0};
+}
+// absorb the full blocks of msg[0, upto) that `mid` has not seen yet
+static inline void sha_mid_advance(ShaMid& mid, const uint8_t* msg, size_t upto) {
+  size_t full = upto & ~(size_t)63;
+  if (full > mid.done) {
+    sha256_blocks(mid.st, msg + mid.done, (full - mid.done) / 64);
+    mid.done = full;
+  }
+}
+// digest of msg[0, len) given the state after its first mid.done bytes; same slack rule as sha256_inplace
+static inline void sha256_resume_inplace(const ShaMid& mid, uint8_t* msg, size_t len, uint8_t out[32]) {
+  uint32_t st[8];
+  memcpy(st, mid.st, sizeof st);
+  size_t total = len;
+  msg[total++] = 0x80;
+  while ((total & 63) != 56) msg[total++] = 0;
+  uint64_t bits = (uint64_t)len * 8;
+  for (int i = 7; i >= 0; i--) msg[total++] = (uint8_t)(bits >> (8 * i));
+  sha256_blocks(st, msg + mid.done, (total - mid.done) / 64);
+  for (int i = 0; i < 8; i++) {
+    out[4 * i] = (uint8_t)(st[i] >> 24);
+    out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(st[i] >> 8);
+    out[4 * i + 3] = (uint8_t)st[i];
+  }
+}
+
 // ---- 256-bit little-endian integer -> decimal text ------------------------------------------
 static inline uint64_t div_u128_u64(uint64_t hi, uint64_t lo, uint64_t d, uint64_t* rem) {
 #if defined(__x86_64__)
@@ -304,13 +339,25 @@ static inline void oracle(uint8_t* msg, size_t len, const uint64_t m[4], uint8_t
   digest_mod(dg, m, out_le);
 }
 
+// state after the first block of `show _r` (78 characters: the first 64 are one SHA block)
+static inline const ShaMid& sha_mid_show_r() {
+  static const ShaMid mid = [] {
+    ShaMid m = sha_mid_init();
+    sha_mid_advance(m, (const uint8_t*)SHOW_R, SHOW_R_LEN);
+    return m;
+  }();
+  return mid;
+}
+
 // Incremental message builder over a caller-provided scratch buffer
 struct Msg {
   uint8_t* buf;
   size_t len;
   ShowStyle st;
+  bool opens_with_r = false;
   Msg(uint8_t* b, ShowStyle s) : buf(b), len(0), st(s) {}
   void r() {
+    if (len == 0) opens_with_r = true;
     memcpy(buf + len, SHOW_R, SHOW_R_LEN);
     len += SHOW_R_LEN;
   }
@@ -320,7 +367,18 @@ struct Msg {
     memcpy(buf + len, p, n);
     len += n;
   }
-  void finish_fr(uint8_t out_le[32]) { oracle(buf, len, MOD_R, out_le); }
+  void finish_fr(uint8_t out_le[32]) {
+    if (opens_with_r)
+      finish_fr_from(sha_mid_show_r(), out_le);
+    else
+      oracle(buf, len, MOD_R, out_le);
+  }
+  // as finish_fr, for a message whose first mid.done bytes are already absorbed in `mid`
+  void finish_fr_from(const ShaMid& mid, uint8_t out_le[32]) {
+    uint8_t dg[32];
+    sha256_resume_inplace(mid, buf, len, dg);
+    digest_mod(dg, MOD_R, out_le);
+  }
 };
 constexpr size_t MSG_SCRATCH = 1280;  // longest transcript: shamirX, 8 numbers + show_r + slack
 
