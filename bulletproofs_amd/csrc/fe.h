@@ -643,6 +643,39 @@ BP_HD void fq_fold_small(u256& r, uint32_t k) {
 }
 
 BP_HD u256 fq_add(const u256& a, const u256& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE_PORTABLE_ADDSUB)
+  // a + b, then + C where the sum wrapped past 2^256 (2^256 = C mod p), then the rare second wrap on three limbs: 23 instructions
+  u256 r;
+  uint32_t k0, k1;
+  asm(
+      "v_add_co_u32 %0, vcc, %10, %18\n\t"
+      "v_addc_co_u32 %1, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %15, %23, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %16, %24, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %17, %25, vcc\n\t"
+      "v_cndmask_b32 %8, 0, %26, vcc\n\t"
+      "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
+      "v_cndmask_b32 %8, 0, %26, vcc\n\t"
+      "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(k0), "=&v"(k1)
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(977u)
+      : "vcc");
+  return r;
+#else
   u256 r;
   uint32_t cy = u256_add(r, a, b);
   // 2^256 = C (mod p): add cy*C with full ripple, then a rare second wrap
@@ -660,9 +693,42 @@ BP_HD u256 fq_add(const u256& a, const u256& b) {
   }
   fq_fold_small(r, (uint32_t)c);
   return r;
+#endif
 }
 
 BP_HD u256 fq_sub(const u256& a, const u256& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE_PORTABLE_ADDSUB)
+  // a - b, then - C where it borrowed (the wrapped value is a - b + 2^256 = a - b + C mod p), then the rare second borrow on two limbs: 22 instructions
+  u256 r;
+  uint32_t k0, k1;
+  asm(
+      "v_sub_co_u32 %0, vcc, %10, %18\n\t"
+      "v_subb_co_u32 %1, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %16, %24, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %17, %25, vcc\n\t"
+      "v_cndmask_b32 %8, 0, %26, vcc\n\t"
+      "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %8\n\t"
+      "v_subb_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_subbrev_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "v_subbrev_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "v_subbrev_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "v_subbrev_co_u32 %5, vcc, 0, %5, vcc\n\t"
+      "v_subbrev_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "v_subbrev_co_u32 %7, vcc, 0, %7, vcc\n\t"
+      "v_cndmask_b32 %8, 0, %26, vcc\n\t"
+      "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %8\n\t"
+      "v_subb_co_u32 %1, vcc, %1, %9, vcc"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(k0), "=&v"(k1)
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(977u)
+      : "vcc");
+  return r;
+#else
   u256 r;
   uint32_t bw = u256_sub(r, a, b);
   // wrapped value is a-b+2^256 = a-b+C (mod p): subtract bw*C
@@ -685,6 +751,7 @@ BP_HD u256 fq_sub(const u256& a, const u256& b) {
   c >>= 32;
   r.v[1] = (uint32_t)((int64_t)r.v[1] - (int64_t)bw2 + c);
   return r;
+#endif
 }
 
 BP_HD u256 fq_neg(const u256& a) { return fq_sub(u256_zero(), a); }
@@ -817,9 +884,154 @@ BP_HD u256 fq_sqr_n(u256 a, int n) {
   return a;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Per-lane masks in an SGPR pair and selects through them: the compiler turns 8-limb ternaries into
+// exec-masked branches full of moves, these stay one v_cndmask per limb.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ uint32_t vsel(lanemask m, uint32_t a, uint32_t b) {  // m ? a : b
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+__device__ __forceinline__ lanemask vmask_even(uint32_t x) {
+  lanemask m;
+  uint32_t t = x & 1u;
+  asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(t));
+  return m;
+}
+// d = a - b; returns the lanes that borrowed (a < b)
+__device__ __forceinline__ lanemask dev_sub8_mask(uint32_t (&d)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+  lanemask m;
+  asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=s"(m)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[1]),
+        "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+      : "vcc");
+  return m;
+}
+// d = a + b (no carry out kept)
+__device__ __forceinline__ void dev_add8_to(uint32_t (&d)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+  asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+      "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[0]), "v"(b[1]),
+        "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+      : "vcc");
+}
+#endif
+
+// Kaliski's almost Montgomery inverse for an odd prime m with 2^255 < m < 2^256 and a in [1, m):
+// returns a^-1 * 2^k mod m and k, 256 <= k <= 512.  Only shifts, adds and selects on 8 limbs
+// (about 120 instructions per step, k = 362 steps on average), against 256 squarings + up to
+// 256 multiplications of a Fermat inversion.  Every step keeps u*s + v*r = m with u, v >= 1, so r and s
+// stay <= m and fit 8 limbs; the classical loop's last step (u = v = 1) is done after the loop.
+BP_HD u256 almost_inverse(const u256& a, const u256& m, uint32_t& k_out) {
+  u256 u = m, v = a, r = u256_zero(), s = u256_one();
+  uint32_t k = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the same step as the portable loop below, spelled as selects: ~130 VALU instructions
+  for (; k < 512; k++) {
+    uint32_t d[8], e[8], x[8], sum[8], keep[8], dbl[8];
+    lanemask lt = dev_sub8_mask(d, u.v, v.v);
+    if ((d[0] | d[1] | d[2] | d[3] | d[4] | d[5] | d[6] | d[7]) == 0u) break;
+    (void)dev_sub8_mask(e, v.v, u.v);
+    lanemask ue = vmask_even(u.v[0]), ve = vmask_even(v.v[0]);
+    // od = ~(ue | ve): both odd, subtract step; us = ue | (od & ~lt): u (and s) change, else v (and r).
+    // Scalar instructions on the masks: C operators on them are compiled as per-lane 64-bit VALU work.
+    lanemask od, us;
+    asm("s_nor_b64 %0, %3, %4\n\t"
+        "s_andn2_b64 %1, %0, %2\n\t"
+        "s_or_b64 %1, %1, %3"
+        : "=&s"(od), "=&s"(us)
+        : "s"(lt), "s"(ue), "s"(ve)
+        : "scc");
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = vsel(od, vsel(lt, e[i], d[i]), vsel(ue, u.v[i], v.v[i]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t xh = (x[i] >> 1) | (i < 7 ? x[i + 1] << 31 : 0u);
+      u.v[i] = vsel(us, xh, u.v[i]);
+      v.v[i] = vsel(us, v.v[i], xh);
+    }
+    dev_add8_to(sum, r.v, s.v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      keep[i] = vsel(od, sum[i], vsel(us, r.v[i], s.v[i]));
+      dbl[i] = vsel(us, s.v[i], r.v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t d2 = (dbl[i] << 1) | (i > 0 ? dbl[i - 1] >> 31 : 0u);
+      r.v[i] = vsel(us, keep[i], d2);
+      s.v[i] = vsel(us, d2, keep[i]);
+    }
+  }
+#else
+  for (; k < 512; k++) {  // 511 steps suffice for gcd(a, m) = 1; the bound makes every lane leave the loop
+    u256 d, e;
+    uint32_t lt = u256_sub(d, u, v);
+    if (u256_is_zero(d)) break;
+    (void)u256_sub(e, v, u);
+    bool ue = (u.v[0] & 1u) == 0, ve = (v.v[0] & 1u) == 0;
+    bool odd2 = !ue && !ve;                // subtract step
+    bool uside = ue || (odd2 && !lt);      // u (and s) change, else v (and r)
+    u256 x, sum;
+    (void)u256_add(sum, r, s);
+#pragma unroll
+    for (int i = 0; i < 8; i++) x.v[i] = odd2 ? (lt ? e.v[i] : d.v[i]) : (ue ? u.v[i] : v.v[i]);
+    u256 xh, r2, s2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      xh.v[i] = (x.v[i] >> 1) | (i < 7 ? x.v[i + 1] << 31 : 0u);
+      r2.v[i] = (r.v[i] << 1) | (i > 0 ? r.v[i - 1] >> 31 : 0u);
+      s2.v[i] = (s.v[i] << 1) | (i > 0 ? s.v[i - 1] >> 31 : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u.v[i] = uside ? xh.v[i] : u.v[i];
+      v.v[i] = uside ? v.v[i] : xh.v[i];
+      uint32_t keep_r = odd2 ? sum.v[i] : r.v[i], keep_s = odd2 ? sum.v[i] : s.v[i];
+      r.v[i] = uside ? keep_r : r2.v[i];
+      s.v[i] = uside ? s2.v[i] : keep_s;
+    }
+  }
+#endif
+  // last step: r <- 2r (mod m), k <- k + 1; the inverse is -r
+  u256 t, t2;
+  uint32_t top = r.v[7] >> 31;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) t.v[i] = (r.v[i] << 1) | (i > 0 ? r.v[i - 1] >> 31 : 0u);
+  uint32_t bw = u256_sub(t2, t, m);
+  if (top || !bw) t = t2;
+  (void)u256_sub(t2, m, t);
+  k_out = k + 1;
+  return t2;
+}
+// 2^e for 0 <= e <= 255
+BP_HD u256 u256_pow2(uint32_t e) {
+  u256 t;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t.v[i] = ((uint32_t)i == (e >> 5)) ? (1u << (e & 31u)) : 0u;
+  return t;
+}
+
 // a^(p-2) by the standard secp256k1 addition chain (255 squarings, 15 mults).
-// fq_inv(0) = 0.
-BP_HD u256 fq_inv(const u256& a) {
+// fq_inv_fermat(0) = 0.
+BP_HD u256 fq_inv_fermat(const u256& a) {
   u256 x2 = fq_mul(fq_sqr(a), a);
   u256 x3 = fq_mul(fq_sqr(x2), a);
   u256 x6 = fq_mul(fq_sqr_n(x3, 3), x3);
@@ -837,6 +1049,31 @@ BP_HD u256 fq_inv(const u256& a) {
   t = fq_mul(fq_sqr_n(t, 3), x2);
   t = fq_mul(fq_sqr_n(t, 2), a);
   return t;
+}
+
+// 1/a mod p, fq_inv(0) = 0: almost inverse a^-1 2^k, then times 2^(512-k) and 2^-512
+BP_HD u256 fq_inv(const u256& a) {
+#ifdef BP_INV_FERMAT
+  return fq_inv_fermat(a);
+#else
+  u256 ac = fq_canon(a);
+  if (u256_is_zero(ac)) return u256_zero();
+  uint32_t k;
+  u256 x = almost_inverse(ac, fq_p(), k);
+  uint32_t e = 512u - k;  // 0..256
+  u256 t = u256_pow2(e & 255u);
+  if (e == 256u) {  // 2^256 = 2^32 + 977 (mod p)
+    t = u256_zero();
+    t.v[0] = 977u;
+    t.v[1] = 1u;
+  }
+  constexpr uint32_t c[8] = {0x0A7244F9u, 0xAC91B0BEu, 0x2A7F3BB9u, 0xB6421533u,
+                             0x0C0528C7u, 0x9606E13Du, 0x9F714620u, 0x35C23D44u};  // 2^-512 mod p
+  u256 c512;
+#pragma unroll
+  for (int i = 0; i < 8; i++) c512.v[i] = c[i];
+  return fq_mul(fq_mul(x, t), c512);
+#endif
 }
 
 // a^((p+1)/4): square root candidate (p = 3 mod 4).  Caller checks r^2 == a.
@@ -977,10 +1214,28 @@ struct Mont {
     return r;
   }
   // a^(m-2); inv(0) = 0
-  static BP_HD u256 inv(const u256& a) {
+  static BP_HD u256 inv_fermat(const u256& a) {
     u256 e = modulus();
     e.v[0] -= 2;  // low limb of both moduli is >= 2
     return pow(a, e);
+  }
+  // Montgomery inverse: a = A R  ->  A^-1 R, inv(0) = 0.  almost_inverse gives a^-1 2^k; one Montgomery
+  // product with 2^(512-k) makes it a^-1 R, one with R^2 makes it a^-1 R^2 = A^-1 R.
+  static BP_HD u256 inv(const u256& a) {
+#ifdef BP_INV_FERMAT
+    return inv_fermat(a);
+#else
+    if (u256_is_zero(a)) return u256_zero();
+    uint32_t k;
+    u256 x = almost_inverse(a, modulus(), k);
+    uint32_t e = 512u - k;  // 0..256
+    u256 t = u256_pow2(e & 255u);
+    if (e == 256u) t = one();
+    u256 r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.v[i] = M::r2(i);
+    return mul(mul(x, t), r2);
+#endif
   }
   // reduce an arbitrary 256-bit integer (< 2^256 < 2m) to canonical
   static BP_HD u256 reduce_once(const u256& a) {

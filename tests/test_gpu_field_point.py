@@ -22,8 +22,30 @@ def test_field_ops_exact(engine, field, mod):
     assert engine.field_op(field, 2, a, b) == [(x * y) % mod for x, y in zip(a, b)]
     assert engine.field_op(field, 3, a) == [x * x % mod for x in a]
     assert engine.field_op(field, 5, a) == [(-x) % mod for x in a]
-    inv = engine.field_op(field, 4, a[:300])
-    assert inv == [pow(x, -1, mod) if x else 0 for x in a[:300]]
+    # inversion (almost Montgomery inverse + 2^-k correction): powers of two and their negatives drive the
+    # step count k to both ends of [256, 512]
+    ai = a[:600] + [2**i % mod for i in range(256)] + [(mod - 2**i) % mod for i in range(0, 256, 3)] + [3, 5, (mod + 1) // 2]
+    inv = engine.field_op(field, 4, ai)
+    assert inv == [pow(x, -1, mod) if x else 0 for x in ai]
+
+
+def test_fq_weakly_reduced_inputs(engine):
+    """The kernels keep Fq values weakly reduced (any 256-bit representative); add/sub fold the wrap past
+    2^256 back with 2^256 = 2^32 + 977 (mod p), twice in the rare cases these inputs force."""
+    C = 2**32 + 977
+    top = 2**256
+    vals = [0, 1, 976, 977, 978, C - 1, C, C + 1, 2 * C - 1, 2 * C, 2 * C + 1, 2**33, 2**64 - 1, P - 1, P, P + 1,
+            top - 2 * C - 1, top - 2 * C, top - C - 1, top - C, top - C + 1, top - 978, top - 977, top - 2, top - 1,
+            2**255, 2**255 + C]
+    rng = random.Random(77)
+    vals += [rng.randrange(top) for _ in range(40)] + [top - 1 - rng.randrange(2 * C) for _ in range(20)]
+    a = [x for x in vals for _ in vals]
+    b = [y for _ in vals for y in vals]
+    assert engine.field_op(0, 0, a, b) == [(x + y) % P for x, y in zip(a, b)]
+    assert engine.field_op(0, 1, a, b) == [(x - y) % P for x, y in zip(a, b)]
+    assert engine.field_op(0, 2, a, b) == [(x * y) % P for x, y in zip(a, b)]
+    assert engine.field_op(0, 5, vals) == [(-x) % P for x in vals]
+    assert engine.field_op(0, 4, vals) == [pow(x % P, -1, P) if x % P else 0 for x in vals]
 
 
 def test_field_laws(engine):
