@@ -24,9 +24,13 @@ pts = np.concatenate([np.tile(np.frombuffer(_lib.enc_point(p), dtype=np.uint8), 
 scv = sc.reshape(5, B, 32); scv[2, ::100, 0] ^= 1
 job = eng.vjob(64, 1, B, a.chunks, a.threads)
 job.load(sc.tobytes(), pts.tobytes())
+times = []
 for it in range(a.iters):
     t0 = time.perf_counter(); v = job.run(); dt = time.perf_counter() - t0
+    times.append(dt)
     ok = np.frombuffer(v, dtype=np.uint8)
     exp = np.ones(B, dtype=np.uint8); exp[::100] = 0
     print(json.dumps(dict(batch=B, chunks=a.chunks, threads=a.threads, s=dt, verifies_per_s=B / dt, correct=bool((ok == exp).all()))), flush=True)
+ts = sorted(times[1:]) or times
+print(json.dumps(dict(summary=True, iters=len(times), min_ms=ts[0] * 1e3, median_ms=ts[len(ts) // 2] * 1e3)), flush=True)
 job.close()

@@ -136,39 +136,47 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
   bool live = p < B;
   xyzz acc = xyzz_inf();
   if (live) {
+    // The lpp lanes of a proof share its nterms x W (term, window) digits round-robin: lane `sub` takes the
+    // flat indices sub, sub + lpp, ... (splitting by whole terms left up to lpp - 1 term slots idle per launch).
+    // The digit and the table row of the next index are fetched before the current mixed add.
+    const uint32_t nf = nterms * (uint32_t)W;
+    auto fetch = [&](uint32_t f, uint32_t& code, size_t& row) {
+      uint32_t term = f / (uint32_t)W, w = f - term * (uint32_t)W;
+      uint32_t g = w / (uint32_t)PER, b = w - g * (uint32_t)PER;
+      uint32_t word = dig[((size_t)term * DW + g) * B + p];
+      code = SLOT == 32 ? word : ((word >> ((SLOT * b) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
+      row = ((size_t)term_base[term] * W + w) * E;
+    };
     affine p0 = affine_inf(), p1 = affine_inf();  // fetched, not yet added (two gathers in flight)
     bool n0 = false, n1 = false;
     int cnt = 0;
-    for (uint32_t term = sub; term < nterms; term += lpp) {
-      const uint8_t* rows = table + (size_t)term_base[term] * W * E * 64;
+    uint32_t f = sub, code_next = 0;
+    size_t row_next = 0;
+    if (f < nf) fetch(f, code_next, row_next);
 #pragma unroll 1
-      for (int g = 0; g < DW; g++) {
-        uint32_t word = dig[((size_t)term * DW + g) * B + p];
-        if (word == 0) continue;
-#pragma unroll 1
-        for (int b = 0; b < PER; b++) {
-          uint32_t code = SLOT == 32 ? word : ((word >> ((SLOT * b) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
-          if (code == 0) continue;
-          int w = PER * g + b;
-          bool neg;
-          uint32_t mag = fb_decode<WB>(code, neg);
-          affine q = ld_affine(rows + ((size_t)w * E + (mag - 1)) * 64);
-          if (cnt == 2) {
-            bucket_add(acc, p0, n0);
-            p0 = p1;
-            n0 = n1;
-            p1 = q;
-            n1 = neg;
-          } else if (cnt == 1) {
-            p1 = q;
-            n1 = neg;
-            cnt = 2;
-          } else {
-            p0 = q;
-            n0 = neg;
-            cnt = 1;
-          }
-        }
+    while (f < nf) {
+      uint32_t code = code_next;
+      size_t row = row_next;
+      f += lpp;
+      if (f < nf) fetch(f, code_next, row_next);
+      if (code == 0) continue;
+      bool neg;
+      uint32_t mag = fb_decode<WB>(code, neg);
+      affine q = ld_affine(table + (row + (mag - 1)) * 64);
+      if (cnt == 2) {
+        bucket_add(acc, p0, n0);
+        p0 = p1;
+        n0 = n1;
+        p1 = q;
+        n1 = neg;
+      } else if (cnt == 1) {
+        p1 = q;
+        n1 = neg;
+        cnt = 2;
+      } else {
+        p0 = q;
+        n0 = neg;
+        cnt = 1;
       }
     }
     if (cnt >= 1) bucket_add(acc, p0, n0);
