@@ -245,51 +245,63 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
 #define TRACE(what, c, r, t0) do { if (trace) fprintf(stderr, "[vjob] %-8s chunk %d round %d  %8.3f -> %8.3f ms\n", what, (int)(c), (int)(r), t0, now_ms()); } while (0)
   const ShaMid r_mid = sha_mid_show_r();  // every transcript opens with the first block of `show _r`
   // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
+  // Two proofs are hashed side by side (finish_fr_pair: interleaved SHA-256 chains); a lone last proof pairs
+  // with itself in spare buffers.
   auto hash0 = [&](Chunk& ch) {
     const size_t B = ch.B;
     job->pool->run(
         [&](size_t a, size_t b) {
-          uint8_t buf[MSG_SCRATCH];
-          for (size_t p = a; p < b; p++) {
-            const uint8_t* A = ch.pts + ((size_t)VP_A * B + p) * 64;
-            const uint8_t* S = ch.pts + ((size_t)VP_S * B + p) * 64;
-            const uint8_t* T1 = ch.pts + ((size_t)VP_T1 * B + p) * 64;
-            const uint8_t* T2 = ch.pts + ((size_t)VP_T2 * B + p) * 64;
-            uint8_t* y = ch.chal + (0 * B + p) * 32;
-            uint8_t* z = ch.chal + (1 * B + p) * 32;
-            uint8_t* x = ch.chal + (2 * B + p) * 32;
-            uint8_t* u = ch.chal + (3 * B + p) * 32;
-            // shamirY: show _r <> A <> S   (Utils.hs:145-148)
-            Msg my(buf, st);
-            my.r();
-            my.point(A);
-            my.point(S);
-            // the text of show _r <> A <> S opens all three messages: its full SHA blocks are absorbed once,
-            // and it stays in place in `buf` (padding is only ever written behind it)
-            const size_t as_len = my.len;
-            ShaMid mid = r_mid;
-            sha_mid_advance(mid, buf, as_len);
-            my.finish_fr_from(mid, y);
+          uint8_t buf0[MSG_SCRATCH], buf1[MSG_SCRATCH];
+          uint8_t spare[4][32];
+          for (size_t p = a; p < b; p += 2) {
+            const bool two = p + 1 < b;
+            const size_t q = two ? p + 1 : p;
+            uint8_t* bufs[2] = {buf0, buf1};
+            const size_t pr[2] = {p, q};
+            uint8_t* y[2] = {ch.chal + (0 * B + p) * 32, two ? ch.chal + (0 * B + q) * 32 : spare[0]};
+            uint8_t* z[2] = {ch.chal + (1 * B + p) * 32, two ? ch.chal + (1 * B + q) * 32 : spare[1]};
+            uint8_t* x[2] = {ch.chal + (2 * B + p) * 32, two ? ch.chal + (2 * B + q) * 32 : spare[2]};
+            uint8_t* u[2] = {ch.chal + (3 * B + p) * 32, two ? ch.chal + (3 * B + q) * 32 : spare[3]};
+            // shamirY: show _r <> A <> S   (Utils.hs:145-148).  The text of show _r <> A <> S opens all three
+            // messages: its full SHA blocks are absorbed once, and it stays in place in the buffer (padding
+            // is only ever written behind it)
+            Msg my[2] = {Msg(bufs[0], st), Msg(bufs[1], st)};
+            ShaMid mid[2] = {r_mid, r_mid};
+            size_t as_len[2];
+            for (int i = 0; i < 2; i++) {
+              my[i].r();
+              my[i].point(ch.pts + ((size_t)VP_A * B + pr[i]) * 64);
+              my[i].point(ch.pts + ((size_t)VP_S * B + pr[i]) * 64);
+              as_len[i] = my[i].len;
+              sha_mid_advance(mid[i], bufs[i], as_len[i]);
+            }
+            finish_fr_pair(my[0], mid[0], y[0], my[1], mid[1], y[1]);
             // shamirZ: ... <> show y   (Utils.hs:150-153)
-            Msg mz(buf, st);
-            mz.len = as_len;
-            mz.fr(y);
-            mz.finish_fr_from(mid, z);
+            Msg mz[2] = {Msg(bufs[0], st), Msg(bufs[1], st)};
+            for (int i = 0; i < 2; i++) {
+              mz[i].len = as_len[i];
+              mz[i].fr(y[i]);
+            }
+            finish_fr_pair(mz[0], mid[0], z[0], mz[1], mid[1], z[1]);
             // shamirX: show _r <> A <> S <> T1 <> T2 <> show y <> show z   (Utils.hs:155-165)
-            Msg mx(buf, st);
-            mx.len = as_len;
-            mx.point(T1);
-            mx.point(T2);
-            mx.fr(y);
-            mx.fr(z);
-            mx.finish_fr_from(mid, x);
+            Msg mx[2] = {Msg(bufs[0], st), Msg(bufs[1], st)};
+            for (int i = 0; i < 2; i++) {
+              mx[i].len = as_len[i];
+              mx[i].point(ch.pts + ((size_t)VP_T1 * B + pr[i]) * 64);
+              mx[i].point(ch.pts + ((size_t)VP_T2 * B + pr[i]) * 64);
+              mx[i].fr(y[i]);
+              mx[i].fr(z[i]);
+            }
+            finish_fr_pair(mx[0], mid[0], x[0], mx[1], mid[1], x[1]);
             // shamirU: show _r <> show tBlinding <> show mu <> show t   (Utils.hs:172-174)
-            Msg mu(buf, st);
-            mu.r();
-            mu.fr(ch.sc + ((size_t)VS_TAU * B + p) * 32);
-            mu.fr(ch.sc + ((size_t)VS_MU * B + p) * 32);
-            mu.fr(ch.sc + ((size_t)VS_T * B + p) * 32);
-            mu.finish_fr_from(r_mid, u);
+            Msg mu[2] = {Msg(bufs[0], st), Msg(bufs[1], st)};
+            for (int i = 0; i < 2; i++) {
+              mu[i].r();
+              mu[i].fr(ch.sc + ((size_t)VS_TAU * B + pr[i]) * 32);
+              mu[i].fr(ch.sc + ((size_t)VS_MU * B + pr[i]) * 32);
+              mu[i].fr(ch.sc + ((size_t)VS_T * B + pr[i]) * 32);
+            }
+            finish_fr_pair(mu[0], r_mid, u[0], mu[1], r_mid, u[1]);
           }
         },
         B);
@@ -299,14 +311,19 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
     const size_t B = ch.B;
     job->pool->run(
         [&](size_t a, size_t b) {
-          uint8_t buf[MSG_SCRATCH];
-          for (size_t p = a; p < b; p++) {
-            Msg mm(buf, st);
-            mm.r();
-            mm.point(ch.pts + ((size_t)(VP_L0 + r) * B + p) * 64);
-            mm.point(ch.pts + ((size_t)(VP_L0 + k + r) * B + p) * 64);
-            mm.point(ch.acc + p * 64);
-            mm.finish_fr_from(r_mid, ch.xk + p * 32);
+          uint8_t buf0[MSG_SCRATCH], buf1[MSG_SCRATCH];
+          uint8_t spare[32];
+          for (size_t p = a; p < b; p += 2) {
+            const bool two = p + 1 < b;
+            const size_t pr[2] = {p, two ? p + 1 : p};
+            Msg mm[2] = {Msg(buf0, st), Msg(buf1, st)};
+            for (int i = 0; i < 2; i++) {
+              mm[i].r();
+              mm[i].point(ch.pts + ((size_t)(VP_L0 + r) * B + pr[i]) * 64);
+              mm[i].point(ch.pts + ((size_t)(VP_L0 + k + r) * B + pr[i]) * 64);
+              mm[i].point(ch.acc + pr[i] * 64);
+            }
+            finish_fr_pair(mm[0], r_mid, ch.xk + p * 32, mm[1], r_mid, two ? ch.xk + (p + 1) * 32 : spare);
           }
         },
         B);

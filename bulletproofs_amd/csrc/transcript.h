@@ -111,6 +111,83 @@ __attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_sha
   _mm_storeu_si128((__m128i*)&st[0], s0);
   _mm_storeu_si128((__m128i*)&st[4], s1);
 }
+// Two independent messages in lock-step: sha256rnds2 has a multi-cycle latency and a message is one
+// dependent chain of 32 of them per block, so a second chain interleaved with it nearly doubles the
+// throughput of a core.
+#define BP_SHA_LOAD_STATE(ST, S0, S1)                               \
+  {                                                                 \
+    __m128i t_ = _mm_loadu_si128((const __m128i*)&(ST)[0]);         \
+    S1 = _mm_loadu_si128((const __m128i*)&(ST)[4]);                 \
+    t_ = _mm_shuffle_epi32(t_, 0xB1);                               \
+    S1 = _mm_shuffle_epi32(S1, 0x1B);                               \
+    S0 = _mm_alignr_epi8(t_, S1, 8);                                \
+    S1 = _mm_blend_epi16(S1, t_, 0xF0);                             \
+  }
+#define BP_SHA_STORE_STATE(ST, S0, S1)                              \
+  {                                                                 \
+    __m128i t_ = _mm_shuffle_epi32(S0, 0x1B);                       \
+    __m128i u_ = _mm_shuffle_epi32(S1, 0xB1);                       \
+    _mm_storeu_si128((__m128i*)&(ST)[0], _mm_blend_epi16(t_, u_, 0xF0)); \
+    _mm_storeu_si128((__m128i*)&(ST)[4], _mm_alignr_epi8(u_, t_, 8));    \
+  }
+#define BP_SHA_QROUND2(MA, MB, KOFF)                                  \
+  {                                                                   \
+    __m128i k_ = _mm_loadu_si128((const __m128i*)&SHA_K[KOFF]);       \
+    __m128i ga = _mm_add_epi32(MA, k_), gb = _mm_add_epi32(MB, k_);   \
+    a1 = _mm_sha256rnds2_epu32(a1, a0, ga);                           \
+    b1 = _mm_sha256rnds2_epu32(b1, b0, gb);                           \
+    ga = _mm_shuffle_epi32(ga, 0x0E);                                 \
+    gb = _mm_shuffle_epi32(gb, 0x0E);                                 \
+    a0 = _mm_sha256rnds2_epu32(a0, a1, ga);                           \
+    b0 = _mm_sha256rnds2_epu32(b0, b1, gb);                           \
+  }
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_shani_x2(uint32_t stA[8], const uint8_t* pa,
+                                                                                       uint32_t stB[8], const uint8_t* pb,
+                                                                                       size_t nblk) {
+  const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+  __m128i a0, a1, b0, b1;
+  BP_SHA_LOAD_STATE(stA, a0, a1)
+  BP_SHA_LOAD_STATE(stB, b0, b1)
+  for (; nblk; nblk--, pa += 64, pb += 64) {
+    __m128i sa0 = a0, sa1 = a1, sb0 = b0, sb1 = b1;
+    __m128i x0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 0)), MASK);
+    __m128i x1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 16)), MASK);
+    __m128i x2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 32)), MASK);
+    __m128i x3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 48)), MASK);
+    __m128i y0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 0)), MASK);
+    __m128i y1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 16)), MASK);
+    __m128i y2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 32)), MASK);
+    __m128i y3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 48)), MASK);
+#define BP_SHA_STEP2(W0, W1, W2, W3, V0, V1, V2, V3, KOFF) \
+  BP_SHA_QROUND2(W0, V0, KOFF) BP_SHA_SCHED(W0, W1, W2, W3) BP_SHA_SCHED(V0, V1, V2, V3)
+    BP_SHA_STEP2(x0, x1, x2, x3, y0, y1, y2, y3, 0)
+    BP_SHA_STEP2(x1, x2, x3, x0, y1, y2, y3, y0, 4)
+    BP_SHA_STEP2(x2, x3, x0, x1, y2, y3, y0, y1, 8)
+    BP_SHA_STEP2(x3, x0, x1, x2, y3, y0, y1, y2, 12)
+    BP_SHA_STEP2(x0, x1, x2, x3, y0, y1, y2, y3, 16)
+    BP_SHA_STEP2(x1, x2, x3, x0, y1, y2, y3, y0, 20)
+    BP_SHA_STEP2(x2, x3, x0, x1, y2, y3, y0, y1, 24)
+    BP_SHA_STEP2(x3, x0, x1, x2, y3, y0, y1, y2, 28)
+    BP_SHA_STEP2(x0, x1, x2, x3, y0, y1, y2, y3, 32)
+    BP_SHA_STEP2(x1, x2, x3, x0, y1, y2, y3, y0, 36)
+    BP_SHA_STEP2(x2, x3, x0, x1, y2, y3, y0, y1, 40)
+    BP_SHA_STEP2(x3, x0, x1, x2, y3, y0, y1, y2, 44)
+#undef BP_SHA_STEP2
+    BP_SHA_QROUND2(x0, y0, 48)
+    BP_SHA_QROUND2(x1, y1, 52)
+    BP_SHA_QROUND2(x2, y2, 56)
+    BP_SHA_QROUND2(x3, y3, 60)
+    a0 = _mm_add_epi32(a0, sa0);
+    a1 = _mm_add_epi32(a1, sa1);
+    b0 = _mm_add_epi32(b0, sb0);
+    b1 = _mm_add_epi32(b1, sb1);
+  }
+  BP_SHA_STORE_STATE(stA, a0, a1)
+  BP_SHA_STORE_STATE(stB, b0, b1)
+}
+#undef BP_SHA_QROUND2
+#undef BP_SHA_LOAD_STATE
+#undef BP_SHA_STORE_STATE
 #undef BP_SHA_QROUND
 #undef BP_SHA_SCHED
 static inline bool cpu_has_shani() {
@@ -152,6 +229,18 @@ static inline void sha256_inplace(uint8_t* msg, size_t len, uint8_t out[32]) {
   }
 }
 
+// two messages with the same number of blocks
+static inline void sha256_blocks_x2(uint32_t stA[8], const uint8_t* pa, uint32_t stB[8], const uint8_t* pb, size_t nblk) {
+#if defined(__x86_64__)
+  if (cpu_has_shani()) {
+    sha256_blocks_shani_x2(stA, pa, stB, pb, nblk);
+    return;
+  }
+#endif
+  sha256_blocks_portable(stA, pa, nblk);
+  sha256_blocks_portable(stB, pb, nblk);
+}
+
 // SHA-256 state after the first `done` bytes (a multiple of 64) of a message: transcripts that share a
 // prefix (every message starts with `show _r`; shamirY/Z/X share `show _r <> A <> S`) hash it once
 struct ShaMid {
@@ -187,18 +276,83 @@ static inline void sha256_resume_inplace(const ShaMid& mid, uint8_t* msg, size_t
   }
 }
 
+static inline size_t sha256_pad_inplace(uint8_t* msg, size_t len) {
+  size_t total = len;
+  msg[total++] = 0x80;
+  while ((total & 63) != 56) msg[total++] = 0;
+  uint64_t bits = (uint64_t)len * 8;
+  for (int i = 7; i >= 0; i--) msg[total++] = (uint8_t)(bits >> (8 * i));
+  return total;
+}
+static inline void sha256_digest_out(const uint32_t st[8], uint8_t out[32]) {
+  for (int i = 0; i < 8; i++) {
+    out[4 * i] = (uint8_t)(st[i] >> 24);
+    out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(st[i] >> 8);
+    out[4 * i + 3] = (uint8_t)st[i];
+  }
+}
+// sha256_resume_inplace for two messages at once (their common blocks run interleaved)
+static inline void sha256_resume_inplace_x2(const ShaMid& midA, uint8_t* msgA, size_t lenA, uint8_t outA[32],
+                                            const ShaMid& midB, uint8_t* msgB, size_t lenB, uint8_t outB[32]) {
+  uint32_t sa[8], sb[8];
+  memcpy(sa, midA.st, sizeof sa);
+  memcpy(sb, midB.st, sizeof sb);
+  size_t na = (sha256_pad_inplace(msgA, lenA) - midA.done) / 64, nb = (sha256_pad_inplace(msgB, lenB) - midB.done) / 64;
+  size_t common = na < nb ? na : nb;
+  sha256_blocks_x2(sa, msgA + midA.done, sb, msgB + midB.done, common);
+  if (na > common) sha256_blocks(sa, msgA + midA.done + 64 * common, na - common);
+  if (nb > common) sha256_blocks(sb, msgB + midB.done + 64 * common, nb - common);
+  sha256_digest_out(sa, outA);
+  sha256_digest_out(sb, outB);
+}
+
 // ---- 256-bit little-endian integer -> decimal text ------------------------------------------
-static inline uint64_t div_u128_u64(uint64_t hi, uint64_t lo, uint64_t d, uint64_t* rem) {
-#if defined(__x86_64__)
-  uint64_t q, r;
-  __asm__("divq %4" : "=a"(q), "=d"(r) : "a"(lo), "d"(hi), "r"(d) : "cc");
+// (u1:u0) / 10^19 for u1 < 10^19 by multiplication with a precomputed reciprocal (Moeller-Granlund
+// 2-by-1 division; 10^19 has its top bit set, so it is its own normalised divisor): ~10 cycles
+// against a 128/64-bit `div`.
+static inline uint64_t div_1e19(uint64_t u1, uint64_t u0, uint64_t* rem) {
+  const uint64_t D = 10000000000000000000ULL;
+  const uint64_t V = 0xd83c94fb6d2ac34aULL;  // floor((2^128 - 1) / D) - 2^64
+  unsigned __int128 q = (unsigned __int128)V * u1 + (((unsigned __int128)u1 << 64) | u0);
+  uint64_t q1 = (uint64_t)(q >> 64) + 1, q0 = (uint64_t)q;
+  uint64_t r = u0 - q1 * D;
+  if (r > q0) {
+    q1--;
+    r += D;
+  }
+  if (r >= D) {
+    q1++;
+    r -= D;
+  }
   *rem = r;
-  return q;
-#else
-  unsigned __int128 n = ((unsigned __int128)hi << 64) | lo;
-  *rem = (uint64_t)(n % d);
-  return (uint64_t)(n / d);
-#endif
+  return q1;
+}
+
+static const char DEC_PAIRS[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960"
+    "616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
+// exactly 8 digits of x < 10^8: four independent two-digit lookups
+static inline void put8(char* o, uint32_t x) {
+  uint32_t hi = x / 10000u, lo = x - hi * 10000u;
+  uint32_t a = hi / 100u, b = hi - a * 100u, c = lo / 100u, d = lo - c * 100u;
+  memcpy(o, DEC_PAIRS + 2 * a, 2);
+  memcpy(o + 2, DEC_PAIRS + 2 * b, 2);
+  memcpy(o + 4, DEC_PAIRS + 2 * c, 2);
+  memcpy(o + 6, DEC_PAIRS + 2 * d, 2);
+}
+// exactly 19 digits of c < 10^19: 3 + 8 + 8
+static inline void put19(char* o, uint64_t c) {
+  uint64_t q = c / 100000000ULL;
+  uint32_t e = (uint32_t)(c - q * 100000000ULL);
+  uint32_t a = (uint32_t)(q / 100000000ULL);      // < 1000
+  uint32_t b = (uint32_t)(q - (uint64_t)a * 100000000ULL);
+  uint32_t a1 = a / 100u, a0 = a - a1 * 100u;
+  o[0] = (char)('0' + a1);
+  memcpy(o + 1, DEC_PAIRS + 2 * a0, 2);
+  put8(o + 3, b);
+  put8(o + 11, e);
 }
 
 // writes the decimal digits of the 32-byte LE integer, returns the length (no terminator)
@@ -211,18 +365,14 @@ static inline size_t u256_to_dec(const uint8_t le[32], char* out) {
     out[0] = '0';
     return 1;
   }
-  const uint64_t TEN19 = 10000000000000000000ULL;
   uint64_t chunk[5];
   int nchunk = 0;
   while (top >= 0) {
     uint64_t rem = 0;
-    for (int i = top; i >= 0; i--) v[i] = div_u128_u64(rem, v[i], TEN19, &rem);
+    for (int i = top; i >= 0; i--) v[i] = div_1e19(rem, v[i], &rem);
     chunk[nchunk++] = rem;
     while (top >= 0 && v[top] == 0) top--;
   }
-  static const char D2[201] =
-      "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960"
-      "616263646566676869707172737475767778798081828384858687888990919293949596979899";
   char* o = out;
   // most significant chunk without leading zeros
   {
@@ -235,30 +385,9 @@ static inline size_t u256_to_dec(const uint8_t le[32], char* out) {
     } while (c);
     while (n) *o++ = tmp[--n];
   }
-  // every further chunk is exactly 19 digits: 1 + 9 pairs
+  // every further chunk is exactly 19 digits
   for (int k = nchunk - 2; k >= 0; k--) {
-    uint64_t c = chunk[k];
-    uint32_t lo9 = (uint32_t)(c % 1000000000ULL);
-    uint64_t hi = c / 1000000000ULL;          // 10 digits
-    uint32_t mid9 = (uint32_t)(hi % 1000000000ULL);
-    o[0] = (char)('0' + (uint32_t)(hi / 1000000000ULL));
-    // 9 digits = 1 + 4 pairs, twice
-    uint32_t v = mid9;
-    for (int i = 4; i >= 1; i--) {
-      uint32_t q = v / 100, r2 = v - q * 100;
-      o[2 * i] = D2[2 * r2];
-      o[2 * i + 1] = D2[2 * r2 + 1];
-      v = q;
-    }
-    o[1] = (char)('0' + v);
-    v = lo9;
-    for (int i = 4; i >= 1; i--) {
-      uint32_t q = v / 100, r2 = v - q * 100;
-      o[9 + 2 * i] = D2[2 * r2];
-      o[9 + 2 * i + 1] = D2[2 * r2 + 1];
-      v = q;
-    }
-    o[10] = (char)('0' + v);
+    put19(o, chunk[k]);
     o += 19;
   }
   return (size_t)(o - out);
@@ -380,6 +509,13 @@ struct Msg {
     digest_mod(dg, MOD_R, out_le);
   }
 };
+// finish two messages together (interleaved SHA-256)
+static inline void finish_fr_pair(Msg& a, const ShaMid& ma, uint8_t outa_le[32], Msg& b, const ShaMid& mb, uint8_t outb_le[32]) {
+  uint8_t da[32], db[32];
+  sha256_resume_inplace_x2(ma, a.buf, a.len, da, mb, b.buf, b.len, db);
+  digest_mod(da, MOD_R, outa_le);
+  digest_mod(db, MOD_R, outb_le);
+}
 constexpr size_t MSG_SCRATCH = 1280;  // longest transcript: shamirX, 8 numbers + show_r + slack
 
 }  // namespace host

@@ -130,3 +130,17 @@ extern "C" void hs_glv_multiexp(int np, const uint8_t* ks, const uint8_t* ps, ui
   }
   sta(out, xyzz_to_affine(r));
 }
+
+// ---- host transcript primitives (transcript.h): paired SHA-256 and the decimal writer ----
+#include "../../bulletproofs_amd/csrc/transcript.h"
+// digests of two messages through the interleaved path (skip_a / skip_b full leading blocks are absorbed
+// first, as the batch verifier does with shared prefixes); the buffers need 72 bytes of slack
+extern "C" void hs_sha256_pair(uint8_t* a, size_t la, size_t skip_a, uint8_t* b, size_t lb, size_t skip_b, uint8_t* outa,
+                               uint8_t* outb) {
+  using namespace bp::host;
+  ShaMid ma = sha_mid_init(), mb = sha_mid_init();
+  sha_mid_advance(ma, a, skip_a * 64 < la ? skip_a * 64 : 0);
+  sha_mid_advance(mb, b, skip_b * 64 < lb ? skip_b * 64 : 0);
+  sha256_resume_inplace_x2(ma, a, la, outa, mb, b, lb, outb);
+}
+extern "C" size_t hs_u256_to_dec(const uint8_t* le, char* out) { return bp::host::u256_to_dec(le, out); }

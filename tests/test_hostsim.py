@@ -140,3 +140,30 @@ def test_bucket_msm_bodies(hs, c):
     if c == 7:
         for case in golden()["sumExps"]:
             assert msm(hs, [ux(s) for s in case["scalars"]], [up(q) for q in case["points"]], c) == up(case["result"])
+
+
+def test_paired_sha256_and_decimal_writer(hs):
+    """transcript.h: two messages hashed in lock-step (SHA-NI where the CPU has it) equal hashlib for every
+    combination of lengths around the block and padding boundaries, with and without absorbed prefixes;
+    the reciprocal-division decimal writer equals str()."""
+    import ctypes, hashlib, os, random
+    rng = random.Random(5)
+    lens = [0, 1, 55, 56, 63, 64, 65, 119, 120, 127, 128, 200, 447, 448, 449, 640, 1000]
+    hs.hs_sha256_pair.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                  ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]
+    for la in lens:
+        for lb in lens[::2] + [la]:
+            a = bytes(rng.randrange(256) for _ in range(la))
+            b = bytes(rng.randrange(256) for _ in range(lb))
+            ba = ctypes.create_string_buffer(a + bytes(80), la + 80)
+            bb = ctypes.create_string_buffer(b + bytes(80), lb + 80)
+            oa, ob = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+            hs.hs_sha256_pair(ba, la, rng.randrange(3), bb, lb, rng.randrange(5), oa, ob)
+            assert oa.raw == hashlib.sha256(a).digest() and ob.raw == hashlib.sha256(b).digest(), (la, lb)
+    hs.hs_u256_to_dec.restype = ctypes.c_size_t
+    vals = [0, 1, 9, 10, 10**19 - 1, 10**19, 10**19 + 1, 10**38 - 1, 10**38, 10**57, 10**76, 2**64 - 1, 2**64, 2**128 - 1,
+            2**192, 2**256 - 1, 10**77, 10**77 - 1] + [rng.randrange(2**rng.randrange(1, 257)) for _ in range(3000)]
+    out = ctypes.create_string_buffer(100)
+    for v in vals:
+        n = hs.hs_u256_to_dec(v.to_bytes(32, "little"), out)
+        assert out.raw[:n] == str(v).encode(), v
