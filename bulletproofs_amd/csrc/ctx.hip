@@ -81,6 +81,18 @@ static void build_stream_pool(bp_ctx* ctx) {
   }
 }
 
+hipStream_t ctx_aux_stream(bp_ctx* ctx) {
+  if (ctx->spool.empty()) build_stream_pool(ctx);
+  std::vector<hipStream_t> rest;
+  for (size_t i = 0; i < ctx->spool.size(); i++) {
+    bool in_group = false;
+    for (int g : ctx->sgroup) in_group = in_group || (size_t)g == i;
+    if (!in_group) rest.push_back(ctx->spool[i]);
+  }
+  if (rest.empty()) return ctx->stream;
+  return rest[ctx->aux_next++ % rest.size()];
+}
+
 hipStream_t ctx_chunk_stream(bp_ctx* ctx) {
   if (ctx->spool.empty()) build_stream_pool(ctx);
   if (ctx->sgroup.empty()) return ctx->stream;

@@ -69,6 +69,7 @@ struct bp_ctx {
   std::vector<hipStream_t> spool;
   std::vector<int> sgroup;  // indices into spool that overlap with each other
   size_t spool_next = 0;
+  size_t aux_next = 0;
   int fb_wbits = 8;            // window width of d_table (8, 12 or 16), chosen in bp_ctx_set_generators
   // transcript conventions the reference inherits from un-vendored packages
   int show_style = 0;    // 0: derived Show "A (P x) (P y)" / "P s"; 1: plain "A x y" / "s"
@@ -103,6 +104,8 @@ namespace bp {
 // msm.hip
 // A stream for one chunk of a batch job, from the context's concurrent set (round-robin).  Not owned by the caller.
 hipStream_t ctx_chunk_stream(bp_ctx* ctx);
+// a pool stream outside the concurrent chunk set (side work that nothing on a chunk stream waits for)
+hipStream_t ctx_aux_stream(bp_ctx* ctx);
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz);
 // ipp.hip (device pointers, asynchronous on ctx->stream)

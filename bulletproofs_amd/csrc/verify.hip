@@ -227,6 +227,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                                                     const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
                                                     xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/,
                                                     uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
+  // the host waits for this kernel (it hashes P next): its waves take issue priority over the throughput
+  // kernels of other chunks that share the SIMDs
+  __builtin_amdgcn_s_setprio(3);
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
@@ -246,6 +249,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
                                               u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
                                               xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff,
                                               uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
+  __builtin_amdgcn_s_setprio(3);  // on the host's critical path, like k_stage1_tail
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
@@ -279,9 +283,8 @@ __global__ void __launch_bounds__(256) k_vprep3a(VDims d, const u256* __restrict
 //   term nm + (nm-1-i) (base H_{nm-1-i}): r * s_i * y^-(nm-1-i)        (reverse otherExponents, :38)
 // and for i == 0 the remaining single terms and the variable-base scalars of E2.
 __global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restrict__ sc, const u256* __restrict__ cst,
-                                               const u256* __restrict__ ypowinv, const u256* __restrict__ zpow,
-                                               const u256* __restrict__ xk_m, uint32_t* __restrict__ dig_a,
-                                               uint32_t* __restrict__ dig_b, uint8_t* __restrict__ vs /*[m+2][B][32]*/) {
+                                               const u256* __restrict__ ypowinv, const u256* __restrict__ xk_m,
+                                               uint32_t* __restrict__ dig_a) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t B = d.B;
   if (t >= (size_t)d.nm * B) return;
@@ -297,15 +300,26 @@ __global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restri
   if (i == 0) {
     u256 u = ldm(cst, C_U * B + p);
     put_digits(dig_a, 2 * d.nm, d, p, Fr::from_mont(Fr::mul(Fr::mul(l, r), u)));  // (l r u) G
-    u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
-    u256 tau = Fr::reduce_once(ld_u256(sc + ((size_t)0 * B + p) * 32));
-    put_digits(dig_b, 0, d, p, Fr::from_mont(Fr::sub(tt, ldm(cst, C_DELTA * B + p))));  // (t - delta) G
-    put_digits(dig_b, 1, d, p, tau);                                                    // tau H
-    for (uint32_t j = 0; j < d.m; j++)
-      st_u256(vs + ((size_t)j * B + p) * 32, Fr::from_mont(Fr::neg(ldm(zpow, (size_t)(j + 2) * B + p))));
-    st_u256(vs + ((size_t)d.m * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X * B + p))));
-    st_u256(vs + ((size_t)(d.m + 1) * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X2 * B + p))));
   }
+}
+
+// thread per proof: scalars of the t-polynomial check E2 = (t - delta) G + tau H - sum_j z^(j+2) V_j - x T1 - x^2 T2
+// (verifyTPoly, MultiRangeProof/Verifier.hs:43-65).  They depend on y, z, x only, so this check runs on a side
+// stream while the host is busy with the rounds.
+__global__ void __launch_bounds__(256) k_vprep_t(VDims d, const uint8_t* __restrict__ sc, const u256* __restrict__ cst,
+                                                const u256* __restrict__ zpow, uint32_t* __restrict__ dig_b,
+                                                uint8_t* __restrict__ vs /*[m+2][B][32]*/) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
+  u256 tau = Fr::reduce_once(ld_u256(sc + ((size_t)0 * B + p) * 32));
+  put_digits(dig_b, 0, d, p, Fr::from_mont(Fr::sub(tt, ldm(cst, C_DELTA * B + p))));  // (t - delta) G
+  put_digits(dig_b, 1, d, p, tau);                                                    // tau H
+  for (uint32_t j = 0; j < d.m; j++)
+    st_u256(vs + ((size_t)j * B + p) * 32, Fr::from_mont(Fr::neg(ldm(zpow, (size_t)(j + 2) * B + p))));
+  st_u256(vs + ((size_t)d.m * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X * B + p))));
+  st_u256(vs + ((size_t)(d.m + 1) * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X2 * B + p))));
 }
 
 // acc2 += sum of up to 2 variable-base terms per pass (terms j0, j0+1 of the E2 list:
@@ -365,17 +379,36 @@ static inline void prof_end(bp_vbatch* vb, int slot) {
   vb->ev_pending[slot] = true;
 }
 
+#define VB_GRID_ON(n, strm) dim3((unsigned)((((size_t)(n)) + 255) / 256)), dim3(256), 0, strm
 static inline void launch_fixed(bp_vbatch* vb, size_t nthreads, uint32_t nterms, uint32_t lpp, const uint32_t* dig,
-                                const uint32_t* tb, xyzz* acc) {
+                                const uint32_t* tb, xyzz* acc, hipStream_t strm = nullptr) {
   const uint8_t* table = vb->ctx->d_table;
+  if (!strm) strm = vb->stream;
   if (vb->d.wb == 20)
-    hipLaunchKernelGGL(k_fixed_multiexp<20>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+    hipLaunchKernelGGL(k_fixed_multiexp<20>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
   else if (vb->d.wb == 16)
-    hipLaunchKernelGGL(k_fixed_multiexp<16>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+    hipLaunchKernelGGL(k_fixed_multiexp<16>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
   else if (vb->d.wb == 12)
-    hipLaunchKernelGGL(k_fixed_multiexp<12>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+    hipLaunchKernelGGL(k_fixed_multiexp<12>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
   else
-    hipLaunchKernelGGL(k_fixed_multiexp<8>, VB_GRID(nthreads), vb->d.B, nterms, lpp, dig, tb, table, acc);
+    hipLaunchKernelGGL(k_fixed_multiexp<8>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
+}
+
+// The t-polynomial check: acc2 = (t - delta) G + tau H - sum z^(j+2) V_j - x T1 - x^2 T2.  Needs k_vprep0's
+// constants: the caller launches it on `strm` only once those are complete (same stream, or a later host visit).
+static inline void launch_tcheck(bp_vbatch* vb, hipStream_t strm) {
+  VDims d = vb->d;
+  size_t B = d.B;
+  hipLaunchKernelGGL(k_vprep_t, VB_GRID_ON(B, strm), d, vb->sc, vb->cst, vb->zpow, vb->dig3b, vb->vs);
+  launch_fixed(vb, B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, vb->acc2, strm);
+  uint32_t nv = d.m + 2;
+  uint32_t j = 0;
+  if (nv & 1u) {  // m = 1: three terms, one pass of three
+    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID_ON(B, strm), d, 0u, vb->pts, vb->vs, vb->vtab2, vb->acc2);
+    j = 3;
+  }
+  for (; j < nv; j += 2)
+    hipLaunchKernelGGL(k_var_terms<2>, VB_GRID_ON(B, strm), d, j, vb->pts, vb->vs, vb->vtab2, vb->acc2);
 }
 
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
@@ -395,6 +428,10 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   }
   VDims d = vb->d;
   size_t B = d.B;
+  if (vb->t_pending) {  // begun again before the previous pass finished: its side work still reads the constants
+    BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->t_pending = false;
+  }
   BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
   hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow);
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
@@ -410,6 +447,7 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
+  vb->begun_complete = false;  // set by vbatch_wait
   return BP_OK;
 }
 
@@ -421,6 +459,11 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   }
   VDims d = vb->d;
   size_t B = d.B;
+  if (round == 0 && vb->begun_complete && !vb->t_pending && vb->aux != vb->stream) {
+    // the stream has drained since begin (the caller saw its output), so k_vprep0's constants are in place
+    launch_tcheck(vb, vb->aux);
+    vb->t_pending = true;
+  }
   BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, vb->stream));
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
   hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff,
@@ -440,22 +483,19 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
   VDims d = vb->d;
   size_t B = d.B;
   hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xkinv_m, vb->cst);
-  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->xk_m,
-                     vb->dig3a, vb->dig3b, vb->vs);
+  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->xk_m, vb->dig3a);
   uint32_t lpp = vbatch_lpp(d.B);
   prof_begin(vb, 1, vb->nt3a);
   launch_fixed(vb, B * lpp, vb->nt3a, lpp, vb->dig3a, vb->tb3a, vb->acc1);
   prof_end(vb, 1);
-  prof_begin(vb, 2, vb->nt3b);
-  launch_fixed(vb, B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, vb->acc2);
-  prof_end(vb, 2);
-  uint32_t nv = d.m + 2;
-  uint32_t j = 0;
-  if (nv & 1u) {  // m = 1: three terms, one pass of three
-    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID(B), d, 0u, vb->pts, vb->vs, vb->vtab, vb->acc2);
-    j = 3;
+  if (vb->t_pending) {
+    // launched on the side stream at round 0, many milliseconds ago: this wait is a formality, and it keeps
+    // event/barrier packets (which break the overlap of the chunk streams) out of the queues
+    BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->t_pending = false;
+  } else {
+    launch_tcheck(vb, vb->stream);
   }
-  for (; j < nv; j += 2) hipLaunchKernelGGL(k_var_terms<2>, VB_GRID(B), d, j, vb->pts, vb->vs, vb->vtab, vb->acc2);
   uint8_t* direct = vb->direct_host ? verdicts : nullptr;
   hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict, direct);
   BP_TRY(hipGetLastError());
@@ -471,6 +511,7 @@ bool vbatch_ready(bp_vbatch* vb) { return hipStreamQuery(vb->stream) == hipSucce
 int vbatch_wait(bp_vbatch* vb) {
   bp_ctx* ctx = vb->ctx;
   BP_TRY(hipStreamSynchronize(vb->stream));
+  if (vb->stage == 2) vb->begun_complete = true;
   for (int s = 0; s < 3; s++)
     if (vb->ev_pending[s]) {
       float ms = 0;
@@ -542,10 +583,14 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->acc1 = c.take<xyzz>(B);
     vb->acc2 = c.take<xyzz>(B);
     vb->vtab = c.take<xyzz>((size_t)VT_ENTRIES * B);
+    vb->vtab2 = c.take<xyzz>((size_t)VT_ENTRIES * B);
     return c.off;
   };
   size_t need = carve(nullptr);
   vb->stream = ctx_chunk_stream(ctx);  // from the context's concurrent set; not owned
+  vb->aux = ctx_aux_stream(ctx);
+  vb->t_pending = false;
+  vb->begun_complete = false;
   hipError_t e = hipSuccess;
   vb->done = nullptr;
   e = hipEventCreateWithFlags(&vb->done, hipEventDisableTiming);
@@ -595,6 +640,7 @@ void bp_vbatch_destroy(bp_vbatch* vb) {
   if (!vb) return;
   (void)hipSetDevice(vb->ctx->device);
   (void)hipStreamSynchronize(vb->stream);
+  if (vb->t_pending) (void)hipStreamSynchronize(vb->aux);
   vb->buf.release();
   for (int s = 0; s < 3; s++)
     for (int j = 0; j < 2; j++)
