@@ -406,12 +406,9 @@ static inline size_t show_fr(ShowStyle st, const uint8_t s[32], char* out) {
 
 // `pointToBS = show`  (Utils.hs:32-33); 64 zero bytes encode `O`
 static inline size_t show_point(ShowStyle st, const uint8_t pt[64], char* out) {
-  bool inf = true;
-  for (int i = 0; i < 64; i++)
-    if (pt[i]) {
-      inf = false;
-      break;
-    }
+  uint64_t w[8];
+  memcpy(w, pt, 64);
+  bool inf = (w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0;
   char* o = out;
   if (inf) {
     *o++ = 'O';

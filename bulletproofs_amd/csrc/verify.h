@@ -54,7 +54,7 @@ struct bp_vbatch {
   bp::xyzz *acc1, *acc2, *vtab, *vtab2;  // vtab2: joint tables of the t-check (runs beside the rounds)
   uint32_t nt1, nt3a, nt3b, npts;
   int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
-  // outputs of the *_async calls are pinned host memory the kernels may store to directly
+  // buffers of the *_async calls are pinned host memory: kernels read challenges from and store results to them directly
   bool direct_host;
   // profiling: event pairs around the three k_fixed_multiexp launches
   hipEvent_t ev[3][2];

@@ -432,8 +432,14 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
     BP_TRY(hipStreamSynchronize(vb->aux));
     vb->t_pending = false;
   }
-  BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
-  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow);
+  // pinned caller buffers are read by the kernel itself (one 32-byte read per proof and challenge over the
+  // host link): no copy command enters the queue
+  const uint8_t* chal = challenges;
+  if (!vb->direct_host) {
+    BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
+    chal = vb->chal;
+  }
+  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow);
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   uint32_t lpp = vbatch_lpp(d.B);
   prof_begin(vb, 0, vb->nt1);
@@ -464,9 +470,13 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
     launch_tcheck(vb, vb->aux);
     vb->t_pending = true;
   }
-  BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, vb->stream));
+  const uint8_t* xin = x;
+  if (!vb->direct_host) {
+    BP_TRY(hipMemcpyAsync(vb->xk, x, B * 32, hipMemcpyHostToDevice, vb->stream));
+    xin = vb->xk;
+  }
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
-  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, vb->xk, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff,
+  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, xin, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff,
                      direct);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
