@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/rNN_*: kernel trace + HBM traffic (FETCH_SIZE, WRITE_SIZE in separate passes)
-# + SQ issue counters of the same bench command.  Run on the GPU box from the repo root:  bash benchmarks/profile_round.sh r01c
+# + SQ issue counters of the same bench command.  Run on the GPU box from the repo root:  bash benchmarks/profile_round.sh r01d
 set -e
 TAG=${1:-r01}
 R=$(pwd)
