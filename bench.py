@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=192, help="proofs of the batch timed on the CPU restatement (~16 s on one core)")
     ap.add_argument("--msm-logn", type=int, default=20)
     a = ap.parse_args()
 

@@ -67,6 +67,38 @@ BP_HD void glv_split(const u256& k, GlvHalf& h1, GlvHalf& h2) {
   }
 }
 
+// k (canonical, < r) -> non-negative halves m1, m2 < 2^129 with k = m1 + m2*lambda (mod r).
+// glv_split's signed halves satisfy |k1| < 0.64 * 2^128, |k2| < 0.55 * 2^128 (rounding to the lattice
+// basis (a1, b1), (a2, b2)); adding the lattice vector (a2 - a1, b2 - b1) = (|b1|, a2), which is = 0 under
+// (x, y) -> x + y*lambda, moves both into (0.25, 1.63) * 2^128.  With no signs left, a joint table
+// over P, phi(P), ... depends on the points only and can be built before the scalars are known.
+struct GlvPos {
+  uint32_t m1[5], m2[5];
+};
+BP_HD GlvPos glv_split_pos(const u256& k) {
+  const uint32_t G1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+  const uint32_t G2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+  const uint32_t MB1_M[8] = {0x0AD9263Cu, 0xC50468D0u, 0xFAA6ED42u, 0x1B1C8205u, 0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu};
+  const uint32_t MB2_M[8] = {0x6A144696u, 0x0CAC5E50u, 0xF3BA5939u, 0x1E8A8DC5u, 0xBA244FCEu, 0x176CDF65u, 0x8E173580u, 0xC25575EBu};
+  const uint32_t LAM_M[8] = {0xC9926C9Eu, 0xF07DEB3Du, 0x83C6944Cu, 0x2C93E7ADu, 0x52697D91u, 0x73A96606u, 0x8558D639u, 0x53284017u};
+  const uint32_t OFF1[8] = {0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u, 0u, 0u, 0u, 0u};           // |b1| = a2 - a1
+  const uint32_t OFF2[8] = {0x9D44CFD8u, 0x57C1108Du, 0xA8E2F3F6u, 0x14CA50F7u, 0x00000001u, 0u, 0u, 0u};  // a2 = b2 - b1
+  u256 c1 = glv_mul_shift_384(k, glv_const(G1));
+  u256 c2 = glv_mul_shift_384(k, glv_const(G2));
+  u256 r2 = Fr::add(Fr::mul(c1, glv_const(MB1_M)), Fr::mul(c2, glv_const(MB2_M)));
+  u256 r1 = Fr::sub(k, Fr::mul(r2, glv_const(LAM_M)));
+  // r1, r2 are the signed halves mod r; the offsets bring both into [0, 2^129)
+  r1 = Fr::add(r1, glv_const(OFF1));
+  r2 = Fr::add(r2, glv_const(OFF2));
+  GlvPos g;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    g.m1[i] = r1.v[i];
+    g.m2[i] = r2.v[i];
+  }
+  return g;
+}
+
 // phi(P) = (beta * x, y)
 BP_HD affine glv_phi(const affine& p) {
   const uint32_t BETA[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
@@ -99,6 +131,13 @@ BP_HD uint32_t bitreg_next(BitReg& b) {
   return top;
 }
 constexpr int GLV_BITS = 129;
+BP_HD BitReg bitreg_init5(const uint32_t (&m)[5]) {
+  GlvHalf h;
+#pragma unroll
+  for (int i = 0; i < 5; i++) h.m[i] = m[i];
+  h.neg = false;
+  return bitreg_init(h);
+}
 
 // Joint table over T signed half-terms q[0..T): entry e in [1, 2^T) = sum_{j in bits(e)} q[j], XYZZ.
 // The caller stores the single-term entries (e = 2^j) with xyzz_from_affine(q[j]); this routine then
@@ -136,6 +175,48 @@ BP_HD HalfPair glv_prep_point(const u256& k, const affine& P, int ea, int eb, St
   hp.a = bitreg_init(h1);
   hp.b = bitreg_init(h2);
   return hp;
+}
+
+// k0*P0 + k1*P1 through the sign-free joint table of the pair: load(e), e in [1, 16), returns the AFFINE sum
+// over the bits of e of {P0, phi(P0), P1, phi(P1)} ((0,0) for the identity).  One doubling and one mixed
+// addition per bit; the entry of the next bit is requested before the current step's arithmetic.
+template <class LoadAff>
+BP_HD xyzz glv_pair_multiexp_tab(const u256& k0, const u256& k1, LoadAff load) {
+  GlvPos s0 = glv_split_pos(k0), s1 = glv_split_pos(k1);
+  BitReg b0 = bitreg_init5(s0.m1), b1 = bitreg_init5(s0.m2), b2 = bitreg_init5(s1.m1), b3 = bitreg_init5(s1.m2);
+  auto next_idx = [&]() -> uint32_t {
+    return bitreg_next(b0) | (bitreg_next(b1) << 1) | (bitreg_next(b2) << 2) | (bitreg_next(b3) << 3);
+  };
+  xyzz acc = xyzz_inf();
+  uint32_t idx = next_idx();
+  affine q = affine_inf();
+  if (idx) q = load((int)idx);
+#pragma unroll 1
+  for (int i = 0; i < GLV_BITS; i++) {
+    affine cur = q;
+    q = affine_inf();
+    if (i + 1 < GLV_BITS) {
+      idx = next_idx();
+      if (idx) q = load((int)idx);
+    }
+    acc = xyzz_dbl(acc);
+    acc = xyzz_madd(acc, cur);
+  }
+  return acc;
+}
+
+// Host-testable construction of that table (the device builds it with one shared inversion, verify.hip):
+// tab[e], e in [1, 16); tab[0] unused.
+BP_HD void glv_pair_table_local(const affine& P0, const affine& P1, affine* tab) {
+  xyzz t[16];
+  t[1] = xyzz_from_affine(P0);
+  t[2] = xyzz_from_affine(glv_phi(P0));
+  t[4] = xyzz_from_affine(P1);
+  t[8] = xyzz_from_affine(glv_phi(P1));
+  auto store = [&](int e, const xyzz& v) { t[e] = v; };
+  auto load = [&](int e) { return t[e]; };
+  joint_table_composites<4>(store, load);
+  for (int e = 1; e < 16; e++) tab[e] = xyzz_to_affine(t[e]);
 }
 
 // Host-testable reference of the whole construction for one or two points:

@@ -333,14 +333,25 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
   // spread out in time: while the host hashes later chunks the GPU already runs the final multiexp of
   // earlier ones, and nothing waits for a whole round to finish across chunks.
   const size_t nc = job->chunks.size();
+  static const int sched_bias = [] {
+    const char* e = getenv("BP_SCHED_BIAS");
+    return e ? atoi(e) : -1;
+  }();
   std::vector<uint32_t> stage(nc, 0);
   size_t finished = 0;
   while (finished < nc) {
     int pick = -1;
+    long pick_key = 0;
     for (size_t c = 0; c < nc; c++) {
       if (stage[c] > k + 1) continue;  // verdicts pending or done
       if (stage[c] > 0 && !vbatch_ready(job->chunks[c].vb)) continue;
-      if (pick < 0 || stage[c] > stage[pick]) pick = (int)c;
+      // sched_bias < 0: the ready chunk that is furthest along; otherwise the least advanced one, with chunk c
+      // handicapped by sched_bias * c stages (0: all chunks advance together; large: lowest index first)
+      long key = sched_bias < 0 ? -(long)stage[c] : (long)stage[c] + (long)sched_bias * (long)c;
+      if (pick < 0 || key < pick_key) {
+        pick = (int)c;
+        pick_key = key;
+      }
     }
     if (pick < 0) {
       // nothing to hash right now: collect a chunk whose verdicts are in, else poll until some chunk's

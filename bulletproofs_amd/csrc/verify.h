@@ -46,12 +46,17 @@ struct bp_vbatch {
   hipStream_t stream;
   hipStream_t aux;        // side stream of the t-polynomial check (verifyTPoly), which needs y, z, x only
   bool t_pending;         // that check is in flight on `aux`
+  bool tab_pending;       // the rounds' joint tables (k_round_tables) are in flight on `aux`
   bool begun_complete;    // the begin stage has been waited for (its constants are complete)
   // device
   uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
   bp::u256 *cst, *ypowinv, *zpow, *xk_m, *xkinv_m;
   uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
   bp::xyzz *acc1, *acc2, *vtab, *vtab2;  // vtab2: joint tables of the t-check (runs beside the rounds)
+  // joint tables of the rounds: affine entries, and the XYZZ composites / running products they are normalised from
+  uint8_t* rtab;
+  bp::xyzz* rtx;
+  bp::u256* rpre;
   uint32_t nt1, nt3a, nt3b, npts;
   int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
   // buffers of the *_async calls are pinned host memory: kernels read challenges from and store results to them directly

@@ -243,11 +243,77 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   if (host_out) st_affine(host_out + (size_t)p * 64, out);
 }
 
+// Joint tables of the rounds, built before any challenge is known: for round r the 15 sums over the non-empty
+// subsets of {L_r, phi(L_r), R_r, phi(R_r)} as AFFINE points, rtab[(15 r + e - 1) * B + p] (64 B each).
+// glv_split_pos leaves no signs, so the tables depend on the proof's points only: this kernel runs on the
+// side stream beside stage 1, off the host's critical path, and k_round adds table entries with mixed
+// additions (8M + 2S) instead of building an XYZZ table per round and using full additions (12M + 2S).
+// The 11 composite entries of every round are formed in XYZZ (rtx) and normalised with ONE inversion per
+// proof (Montgomery's trick over all 11 k entries; rpre holds the running products).
+__device__ __forceinline__ int composite_index(int e, int top) { return e - 2 - top; }  // 3,5,6,7,9..15 -> 0..10
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx /*[11 k][B]*/,
+               u256* __restrict__ rpre /*[11 k][B]*/, uint8_t* __restrict__ rtab /*[15 k][B][64]*/) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  const size_t B = d.B, ES = B * 64;  // stride between table entries of one proof
+  u256 run = u256_one();
+#pragma unroll 1
+  for (uint32_t r = 0; r < d.k; r++) {
+    uint8_t* T = rtab + ((size_t)r * 15 * B + p) * 64;
+    affine L = ld_affine(pts + ((size_t)(VP_L0 + r) * B + p) * 64);
+    affine Rp = ld_affine(pts + ((size_t)(VP_L0 + d.k + r) * B + p) * 64);
+    st_affine(T + 0 * ES, L);
+    st_affine(T + 1 * ES, glv_phi(L));
+    st_affine(T + 3 * ES, Rp);
+    st_affine(T + 7 * ES, glv_phi(Rp));
+#pragma unroll 1
+    for (int e = 3; e < 16; e++) {
+      int top = 31 - __builtin_clz((unsigned)e);
+      int rest = e & ~(1 << top);
+      if (rest == 0) continue;
+      affine qt = ld_affine(T + (size_t)((1 << top) - 1) * ES);
+      xyzz base;
+      if ((rest & (rest - 1)) == 0) {
+        base = xyzz_from_affine(ld_affine(T + (size_t)(rest - 1) * ES));
+      } else {
+        int rtop = 31 - __builtin_clz((unsigned)rest);
+        base = ld_xyzz(&rtx[((size_t)r * 11 + composite_index(rest, rtop)) * B + p]);
+      }
+      xyzz v = xyzz_madd(base, qt);
+      size_t slot = ((size_t)r * 11 + composite_index(e, top)) * B + p;
+      st_xyzz(&rtx[slot], v);
+      stm(rpre, slot, run);
+      if (!xyzz_is_inf(v)) run = fq_mul(run, v.ZZZ);
+    }
+  }
+  u256 inv = fq_inv(run);  // run is a product of non-zero ZZZ values
+#pragma unroll 1
+  for (uint32_t rr = d.k; rr-- > 0;) {
+    uint8_t* T = rtab + ((size_t)rr * 15 * B + p) * 64;
+#pragma unroll 1
+    for (int e = 15; e >= 3; e--) {
+      int top = 31 - __builtin_clz((unsigned)e);
+      if ((e & ~(1 << top)) == 0) continue;
+      size_t slot = ((size_t)rr * 11 + composite_index(e, top)) * B + p;
+      xyzz v = ld_xyzz(&rtx[slot]);
+      affine a = affine_inf();
+      if (!xyzz_is_inf(v)) {
+        u256 zi = fq_mul(inv, ldm(rpre, slot));  // 1 / ZZZ of this entry
+        inv = fq_mul(inv, v.ZZZ);
+        a = xyzz_to_affine_with_inv(v, zi);
+      }
+      st_affine(T + (size_t)(e - 1) * ES, a);
+    }
+  }
+}
+
 // one IPP round of mkChallenges: acc <- x^2 L + x^-2 R + acc  (Verifier.hs:47-50)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_round(VDims d, uint32_t round, const uint8_t* __restrict__ pts,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_round(VDims d, uint32_t round,
                                               const uint8_t* __restrict__ xk /*[B][32] canonical*/,
                                               u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
-                                              xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff,
+                                              const uint8_t* __restrict__ rtab, uint8_t* __restrict__ acc_aff,
                                               uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
   __builtin_amdgcn_s_setprio(3);  // on the host's critical path, like k_stage1_tail
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,10 +323,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   u256 xinv = Fr::inv(x);
   stm(xk_m, (size_t)round * B + p, x);
   stm(xkinv_m, (size_t)round * B + p, xinv);
-  u256 k[2] = {Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv))};
-  affine P[2] = {ld_affine(pts + ((size_t)(VP_L0 + round) * B + p) * 64),
-                 ld_affine(pts + ((size_t)(VP_L0 + d.k + round) * B + p) * 64)};
-  xyzz acc = glv_multiexp_dev<2>(k, P, tab, B, p);
+  const uint8_t* T = rtab + ((size_t)round * 15 * B + p) * 64;
+  xyzz acc = glv_pair_multiexp_tab(Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv)),
+                                   [&](int e) { return ld_affine(T + (size_t)(e - 1) * B * 64); });
   acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
   affine out = xyzz_to_affine(acc);
   st_affine(acc_aff + (size_t)p * 64, out);
@@ -428,9 +493,10 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   }
   VDims d = vb->d;
   size_t B = d.B;
-  if (vb->t_pending) {  // begun again before the previous pass finished: its side work still reads the constants
+  if (vb->t_pending || vb->tab_pending) {  // begun again before the previous pass finished: its side work still reads the constants
     BP_TRY(hipStreamSynchronize(vb->aux));
     vb->t_pending = false;
+    vb->tab_pending = false;
   }
   // pinned caller buffers are read by the kernel itself (one 32-byte read per proof and challenge over the
   // host link): no copy command enters the queue
@@ -438,6 +504,11 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   if (!vb->direct_host) {
     BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
     chal = vb->chal;
+  }
+  if (d.k > 0) {
+    // the rounds' joint tables need the proof's points only: side stream, joined by the host before round 0
+    hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
+    vb->tab_pending = true;
   }
   hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow);
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
@@ -465,6 +536,12 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   }
   VDims d = vb->d;
   size_t B = d.B;
+  if (vb->tab_pending) {
+    // launched beside stage 1, several milliseconds ago: a host-side join keeps event/barrier packets
+    // out of the queues (on a shared stream the order alone would do)
+    if (vb->aux != vb->stream) BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->tab_pending = false;
+  }
   if (round == 0 && vb->begun_complete && !vb->t_pending && vb->aux != vb->stream) {
     // the stream has drained since begin (the caller saw its output), so k_vprep0's constants are in place
     launch_tcheck(vb, vb->aux);
@@ -476,8 +553,7 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
     xin = vb->xk;
   }
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
-  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, vb->pts, xin, vb->xk_m, vb->xkinv_m, vb->vtab, vb->acc_aff,
-                     direct);
+  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage++;
@@ -594,12 +670,16 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->acc2 = c.take<xyzz>(B);
     vb->vtab = c.take<xyzz>((size_t)VT_ENTRIES * B);
     vb->vtab2 = c.take<xyzz>((size_t)VT_ENTRIES * B);
+    vb->rtx = c.take<xyzz>((size_t)11 * (d.k ? d.k : 1) * B);
+    vb->rpre = c.take<u256>((size_t)11 * (d.k ? d.k : 1) * B);
+    vb->rtab = c.take<uint8_t>((size_t)15 * (d.k ? d.k : 1) * B * 64);
     return c.off;
   };
   size_t need = carve(nullptr);
   vb->stream = ctx_chunk_stream(ctx);  // from the context's concurrent set; not owned
   vb->aux = ctx_aux_stream(ctx);
   vb->t_pending = false;
+  vb->tab_pending = false;
   vb->begun_complete = false;
   hipError_t e = hipSuccess;
   vb->done = nullptr;
@@ -650,7 +730,7 @@ void bp_vbatch_destroy(bp_vbatch* vb) {
   if (!vb) return;
   (void)hipSetDevice(vb->ctx->device);
   (void)hipStreamSynchronize(vb->stream);
-  if (vb->t_pending) (void)hipStreamSynchronize(vb->aux);
+  if (vb->t_pending || vb->tab_pending) (void)hipStreamSynchronize(vb->aux);
   vb->buf.release();
   for (int s = 0; s < 3; s++)
     for (int j = 0; j < 2; j++)

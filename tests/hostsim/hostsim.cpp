@@ -131,6 +131,20 @@ extern "C" void hs_glv_multiexp(int np, const uint8_t* ks, const uint8_t* ps, ui
   sta(out, xyzz_to_affine(r));
 }
 
+// non-negative halves (32-byte little-endian each)
+extern "C" void hs_glv_split_pos(const uint8_t* k, uint8_t* out1, uint8_t* out2) {
+  GlvPos g = glv_split_pos(ld(k));
+  memset(out1, 0, 32); memset(out2, 0, 32);
+  memcpy(out1, g.m1, 20); memcpy(out2, g.m2, 20);
+}
+// k0*P0 + k1*P1 through the sign-free affine joint table of the pair
+extern "C" void hs_glv_pair_tab(const uint8_t* ks, const uint8_t* ps, uint8_t* out) {
+  affine tab[16];
+  glv_pair_table_local(lda(ps), lda(ps + 64), tab);
+  xyzz r = glv_pair_multiexp_tab(ld(ks), ld(ks + 32), [&](int e) { return tab[e]; });
+  sta(out, xyzz_to_affine(r));
+}
+
 // ---- host transcript primitives (transcript.h): paired SHA-256 and the decimal writer ----
 #include "../../bulletproofs_amd/csrc/transcript.h"
 // digests of two messages through the interleaved path (skip_a / skip_b full leading blocks are absorbed

@@ -119,6 +119,35 @@ def test_group_law_total(hs):
     assert hs.hs_on_curve(pb(G)) == 1 and hs.hs_on_curve(pb((5, 7))) == 0 and hs.hs_on_curve(pb(None)) == 1
 
 
+LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+
+
+def test_glv_positive_split_and_pair_table(hs):
+    """glv.h: k = m1 + m2*lambda (mod r) with 0 <= m1, m2 < 2^129 (no signs, so the joint table of a pair of
+    points is independent of the scalars), and k0*P0 + k1*P1 through that table equals the oracle's
+    addTwoMulP, including identity points, equal and opposite points."""
+    rng = random.Random(77)
+    ks = [0, 1, 2, R - 1, R - 2, LAMBDA, R - LAMBDA, (R - 1) // 2, (R + 1) // 2, 2**128, 2**255] + \
+         [rng.randrange(R) for _ in range(3000)]
+    for k in ks:
+        o1, o2 = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        hs.hs_glv_split_pos(b(k), o1, o2)
+        m1, m2 = int.from_bytes(o1.raw, "little"), int.from_bytes(o2.raw, "little")
+        assert m1 < 2**129 and m2 < 2**129
+        assert (m1 + m2 * LAMBDA - k) % R == 0
+    G = o.GEN
+    A = o.point_mul(G, rng.randrange(1, R))
+    C = o.point_mul(G, rng.randrange(1, R))
+    beta_a = o.point_mul(A, LAMBDA)
+    pairs = [(A, C), (A, A), (A, o.point_neg(A)), (None, C), (A, None), (None, None), (A, beta_a),
+             (A, o.point_neg(beta_a))]
+    for p0, p1 in pairs:
+        for k0, k1 in [(rng.randrange(R), rng.randrange(R)), (0, 0), (1, R - 1), (R - 1, R - 1), (5, 0)]:
+            out = ctypes.create_string_buffer(64)
+            hs.hs_glv_pair_tab(b(k0) + b(k1), pb(p0) + pb(p1), out)
+            assert dp(out.raw) == o.add_two_mul_p(k0, p0, k1, p1)
+
+
 def msm(hs, es, ps, c):
     out = ctypes.create_string_buffer(64)
     hs.hs_msm(b"".join(b(e) for e in es), b"".join(pb(p) for p in ps), len(es), c, out)
