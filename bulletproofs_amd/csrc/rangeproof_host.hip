@@ -107,6 +107,8 @@ struct Chunk {
   size_t first = 0;     // index of its first proof in the job
   // pinned host memory
   uint8_t *sc = nullptr, *pts = nullptr, *chal = nullptr, *xk = nullptr, *acc = nullptr, *verdict = nullptr;
+  // decimal text written by the kernels (dec.h records): the running commitment, and the rows L_r, R_r
+  uint8_t *acc_txt = nullptr, *lr_txt = nullptr;
 };
 
 }  // namespace
@@ -179,7 +181,8 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     }
     job->k = bp_vbatch_rounds(ch.vb);
     job->npts = bp_vbatch_point_rows(ch.vb);
-    pinned_bytes += (size_t)ch.B * (5 * 32 + (size_t)job->npts * 64 + 4 * 32 + 32 + 64 + 1) + 6 * 256;
+    pinned_bytes += (size_t)ch.B * (5 * 32 + (size_t)job->npts * 64 + 4 * 32 + 32 + 64 + 1 + 160 +
+                                    (size_t)2 * job->k * 160) + 8 * 256;
   }
   if (hipHostMalloc(&job->pinned, pinned_bytes, hipHostMallocDefault) != hipSuccess) {
     job->pinned = nullptr;
@@ -196,6 +199,8 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     ch.xk = cv.take<uint8_t>(B * 32);
     ch.acc = cv.take<uint8_t>(B * 64);
     ch.verdict = cv.take<uint8_t>(B);
+    ch.acc_txt = cv.take<uint8_t>(B * 160);
+    ch.lr_txt = cv.take<uint8_t>((size_t)2 * job->k * B * 160 + 16);
     ch.vb->direct_host = true;  // acc / verdict above are pinned: the kernels store to them directly
   }
   *out = job;
@@ -318,10 +323,12 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
             const size_t pr[2] = {p, two ? p + 1 : p};
             Msg mm[2] = {Msg(buf0, st), Msg(buf1, st)};
             for (int i = 0; i < 2; i++) {
+              // every number of this message was formatted on the GPU (dec.h records): L_r, R_r beside
+              // stage 1, the running commitment by the kernel that produced it
               mm[i].r();
-              mm[i].point(ch.pts + ((size_t)(VP_L0 + r) * B + pr[i]) * 64);
-              mm[i].point(ch.pts + ((size_t)(VP_L0 + k + r) * B + pr[i]) * 64);
-              mm[i].point(ch.acc + pr[i] * 64);
+              mm[i].point_rec(ch.lr_txt + ((size_t)r * B + pr[i]) * 160);
+              mm[i].point_rec(ch.lr_txt + ((size_t)(k + r) * B + pr[i]) * 160);
+              mm[i].point_rec(ch.acc_txt + pr[i] * 160);
             }
             finish_fr_pair(mm[0], r_mid, ch.xk + p * 32, mm[1], r_mid, two ? ch.xk + (p + 1) * 32 : spare);
           }
@@ -333,6 +340,11 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
   // spread out in time: while the host hashes later chunks the GPU already runs the final multiexp of
   // earlier ones, and nothing waits for a whole round to finish across chunks.
   const size_t nc = job->chunks.size();
+  // challenge-independent GPU work of every chunk first (the rounds' joint tables, the text of L_r, R_r): it
+  // fills the GPU while the host hashes the first chunk's y, z, x, u.  (Formatting A, S, T1, T2, tBlinding, mu, t
+  // on the GPU as well was measured slower: the first chunk then waits for its text, 31.9 against 31.0 ms.)
+  for (auto& ch : job->chunks)
+    if ((rc = vbatch_prepare_async(ch.vb, ch.lr_txt)) != BP_OK) return rc;
   static const int sched_bias = [] {
     const char* e = getenv("BP_SCHED_BIAS");
     return e ? atoi(e) : -1;
@@ -375,13 +387,13 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
     if (stage[pick] == 0) {
       hash0(ch);
       TRACE("hash0", pick, -1, t_h);
-      if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc)) != BP_OK) return rc;
+      if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc, ch.acc_txt, ch.lr_txt)) != BP_OK) return rc;
     } else if (stage[pick] <= k) {
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;  // completed already: folds the profiling events in
       uint32_t r = stage[pick] - 1;
       hashR(ch, r);
       TRACE("hashR", pick, r, t_h);
-      if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc)) != BP_OK) return rc;
+      if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc, ch.acc_txt)) != BP_OK) return rc;
     } else {
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
       if ((rc = vbatch_finish_async(ch.vb, ch.verdict)) != BP_OK) return rc;

@@ -432,6 +432,47 @@ static inline size_t show_point(ShowStyle st, const uint8_t pt[64], char* out) {
   return (size_t)(o - out);
 }
 
+// The same texts from numbers the GPU has already formatted (dec.h: 80-byte records, byte 0 = digit count n,
+// digits right-aligned in [80 - n, 80)); the host only concatenates.
+static inline size_t put_dec_record(const uint8_t* rec, char* out) {
+  size_t n = rec[0];
+  memcpy(out, rec + 80 - n, n);
+  return n;
+}
+static inline bool dec_record_is_zero(const uint8_t* rec) { return rec[0] == 1 && rec[79] == '0'; }
+static inline size_t show_fr_rec(ShowStyle st, const uint8_t* rec, char* out) {
+  char* o = out;
+  if (st == SHOW_DERIVED) {
+    *o++ = 'P';
+    *o++ = ' ';
+  }
+  o += put_dec_record(rec, o);
+  return (size_t)(o - out);
+}
+static inline size_t show_point_rec(ShowStyle st, const uint8_t* recx, const uint8_t* recy, char* out) {
+  char* o = out;
+  if (dec_record_is_zero(recx) && dec_record_is_zero(recy)) {  // (0, 0) encodes `O`
+    *o++ = 'O';
+    return 1;
+  }
+  if (st == SHOW_DERIVED) {
+    memcpy(o, "A (P ", 5);
+    o += 5;
+    o += put_dec_record(recx, o);
+    memcpy(o, ") (P ", 5);
+    o += 5;
+    o += put_dec_record(recy, o);
+    *o++ = ')';
+  } else {
+    *o++ = 'A';
+    *o++ = ' ';
+    o += put_dec_record(recx, o);
+    *o++ = ' ';
+    o += put_dec_record(recy, o);
+  }
+  return (size_t)(o - out);
+}
+
 static const char SHOW_R[] = "115792089237316195423570985008687907852837564279074904382605163141518161494337";
 static const size_t SHOW_R_LEN = sizeof(SHOW_R) - 1;
 // little-endian 64-bit limbs
@@ -489,6 +530,9 @@ struct Msg {
   }
   void point(const uint8_t* p) { len += show_point(st, p, (char*)buf + len); }
   void fr(const uint8_t* s) { len += show_fr(st, s, (char*)buf + len); }
+  // the same from GPU-formatted records (a point is two consecutive records: x, y)
+  void point_rec(const uint8_t* rec2) { len += show_point_rec(st, rec2, rec2 + 80, (char*)buf + len); }
+  void fr_rec(const uint8_t* rec) { len += show_fr_rec(st, rec, (char*)buf + len); }
   void raw(const void* p, size_t n) {
     memcpy(buf + len, p, n);
     len += n;

@@ -72,8 +72,14 @@ namespace bp {
 // Asynchronous forms (enqueue on vb->stream, no synchronisation); the host buffers
 // must stay valid until the stream has been synchronised (use pinned memory for overlap).
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points);
-int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment);
-int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment);
+// out_text (pinned, [B][2][80], or null): the decimal text of the commitment's coordinates as dec.h records, for
+// the host's transcript; lr_text (pinned, [2k][B][2][80], or null): the same for the proof's L_r, R_r rows, complete
+// once round 0 has been enqueued (ignored when vbatch_prepare_async has run for this pass).  Both need direct_host.
+int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment, uint8_t* out_text,
+                       uint8_t* lr_text);
+int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment, uint8_t* out_text);
+// the pass's challenge-independent side work (L_r, R_r text into lr_text, the rounds' joint tables), ahead of begin
+int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
 int vbatch_wait(bp_vbatch* vb);
 // has everything enqueued by the last *_async call completed?  (non-blocking)

@@ -16,6 +16,8 @@
 // Data layout: every per-proof array is [field][proof] (proof fastest) so a wave
 // of 64 proofs reads and writes contiguous lines.
 #include "engine.h"
+#include "batchinv.h"
+#include "dec.h"
 #include "devio.h"
 #include "fixedbase.h"
 #include "glv.h"
@@ -52,14 +54,16 @@ __device__ __forceinline__ void put_digits(uint32_t* dig, uint32_t term, const V
 __global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restrict__ chal /*[4][B][32]*/,
                                                u256* __restrict__ cst, u256* __restrict__ ypowinv /*[nm][B]*/,
                                                u256* __restrict__ zpow /*[m+3][B]*/) {
+  __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.B) return;
   size_t B = d.B;
-  u256 y = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)0 * B + p) * 32)));
+  u256 y = Fr::one();
+  if (p < d.B) y = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)0 * B + p) * 32)));
+  u256 yinv = block_batch_inverse<FrInvOps>(y, inv_lds);  // one inversion per workgroup (batchinv.h)
+  if (p >= d.B) return;
   u256 z = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)1 * B + p) * 32)));
   u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)2 * B + p) * 32)));
   u256 u = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)3 * B + p) * 32)));
-  u256 yinv = Fr::inv(y);
   stm(cst, C_Y * B + p, y);
   stm(cst, C_Z * B + p, z);
   stm(cst, C_X * B + p, x);
@@ -119,6 +123,56 @@ __global__ void __launch_bounds__(256) k_vprep1(VDims d, const uint8_t* __restri
     put_digits(dig, d.nm + 1, d, p, Fr::neg(mu));                                       // -mu * H  (canonical neg)
     put_digits(dig, d.nm + 2, d, p, Fr::from_mont(Fr::mul(tt, ldm(cst, C_U * B + p))));  // t*u * G
   }
+}
+
+// ---- decimal text for the host's transcript (dec.h) ------------------------------------------------
+// Every thread of the block holds NW dwords of records; the block's records are contiguous at `dst`.
+// Staged through LDS so that consecutive lanes store consecutive 16-byte pieces: `dst` is pinned host
+// memory, and lane-strided stores would cross the host link as 16-byte writes.
+template <int NW>
+__device__ __forceinline__ void block_store_records(uint32_t* lds, const uint32_t (&w)[NW], uint8_t* dst,
+                                                    uint32_t valid_threads) {
+#pragma unroll
+  for (int i = 0; i < NW; i++) lds[threadIdx.x * NW + i] = w[i];
+  __syncthreads();
+  const uint4* src = (const uint4*)lds;
+  uint4* out = (uint4*)dst;
+  const uint32_t total = valid_threads * (NW / 4);
+  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) out[i] = src[i];
+  __syncthreads();
+}
+
+// record i = decimal text of the 32-byte little-endian integer i of `src` (a [row][proof] array of
+// scalars, or of points, whose x and y are consecutive integers)
+__global__ void __launch_bounds__(256) k_dec_numbers(const uint8_t* __restrict__ src, uint32_t count,
+                                                    uint8_t* __restrict__ dst) {
+  __shared__ uint32_t lds[256 * DEC_REC_WORDS];
+  const uint32_t first = blockIdx.x * 256u;
+  const uint32_t i = first + threadIdx.x;
+  uint32_t w[DEC_REC_WORDS];
+#pragma unroll
+  for (int j = 0; j < DEC_REC_WORDS; j++) w[j] = 0;
+  if (i < count) u256_to_dec_record(ld_u256(src + (size_t)i * 32), w);
+  const uint32_t valid = count - first < 256u ? count - first : 256u;
+  block_store_records<DEC_REC_WORDS>(lds, w, dst + (size_t)first * DEC_REC, valid);
+}
+
+// x and y records of the block's affine results (identity = "0", "0"), to txt[p][2][80]
+__device__ __forceinline__ void block_store_point_text(uint32_t* lds, const affine& a, uint8_t* txt, uint32_t B) {
+  uint32_t w[2 * DEC_REC_WORDS];
+  {
+    uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
+    u256_to_dec_record(a.x, wx);
+    u256_to_dec_record(a.y, wy);
+#pragma unroll
+    for (int j = 0; j < DEC_REC_WORDS; j++) {
+      w[j] = wx[j];
+      w[DEC_REC_WORDS + j] = wy[j];
+    }
+  }
+  const uint32_t first = blockIdx.x * blockDim.x;
+  const uint32_t valid = B - first < blockDim.x ? B - first : blockDim.x;
+  block_store_records<2 * DEC_REC_WORDS>(lds, w, txt + (size_t)first * 2 * DEC_REC, valid);
 }
 
 // ---- fixed-base multi-exponentiation: acc[p] = sum_terms k[term][p] * base(term) ---------
@@ -226,21 +280,33 @@ __device__ __forceinline__ xyzz glv_multiexp_dev(const u256 (&k)[NP], const affi
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
                                                     const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
                                                     xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/,
-                                                    uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
+                                                    uint8_t* __restrict__ host_out /*pinned host copy, or null*/,
+                                                    uint8_t* __restrict__ host_txt /*pinned [B][2][80] decimal text, or null*/) {
+  __shared__ uint32_t lds[256 * 2 * DEC_REC_WORDS];
   // the host waits for this kernel (it hashes P next): its waves take issue priority over the throughput
   // kernels of other chunks that share the SIMDs
   __builtin_amdgcn_s_setprio(3);
+  __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.B) return;
-  size_t B = d.B;
-  u256 k[1] = {Fr::from_mont(ldm(cst, C_X * B + p))};
-  affine P[1] = {ld_affine(pts + ((size_t)VP_S * B + p) * 64)};
-  xyzz acc = glv_multiexp_dev<1>(k, P, tab, B, p);
-  acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
-  acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
-  affine out = xyzz_to_affine(acc);
-  st_affine(acc_aff + (size_t)p * 64, out);
-  if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  const bool live = p < d.B;
+  xyzz acc = xyzz_inf();
+  if (live) {
+    size_t B = d.B;
+    u256 k[1] = {Fr::from_mont(ldm(cst, C_X * B + p))};
+    affine P[1] = {ld_affine(pts + ((size_t)VP_S * B + p) * 64)};
+    acc = glv_multiexp_dev<1>(k, P, tab, B, p);
+    acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
+    acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
+  }
+  // affine form with one inversion per workgroup; the identity (ZZZ = 0) comes back as 0 and stays (0, 0)
+  u256 zi = block_batch_inverse<FqInvOps>(live ? acc.ZZZ : u256_one(), inv_lds);
+  affine out = affine_inf();
+  if (live) {
+    out = xyzz_to_affine_with_inv(acc, zi);
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  }
+  if (host_txt) block_store_point_text(lds, out, host_txt, d.B);  // uniform branch: every thread of the block arrives
 }
 
 // Joint tables of the rounds, built before any challenge is known: for round r the 15 sums over the non-empty
@@ -255,12 +321,13 @@ __device__ __forceinline__ int composite_index(int e, int top) { return e - 2 - 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx /*[11 k][B]*/,
                u256* __restrict__ rpre /*[11 k][B]*/, uint8_t* __restrict__ rtab /*[15 k][B][64]*/) {
+  __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.B) return;
+  const bool live = p < d.B;
   const size_t B = d.B, ES = B * 64;  // stride between table entries of one proof
   u256 run = u256_one();
 #pragma unroll 1
-  for (uint32_t r = 0; r < d.k; r++) {
+  for (uint32_t r = 0; live && r < d.k; r++) {
     uint8_t* T = rtab + ((size_t)r * 15 * B + p) * 64;
     affine L = ld_affine(pts + ((size_t)(VP_L0 + r) * B + p) * 64);
     affine Rp = ld_affine(pts + ((size_t)(VP_L0 + d.k + r) * B + p) * 64);
@@ -288,7 +355,9 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
       if (!xyzz_is_inf(v)) run = fq_mul(run, v.ZZZ);
     }
   }
-  u256 inv = fq_inv(run);  // run is a product of non-zero ZZZ values
+  // run is a product of non-zero ZZZ values; the workgroup shares one inversion (batchinv.h)
+  u256 inv = block_batch_inverse<FqInvOps>(run, inv_lds);
+  if (!live) return;
 #pragma unroll 1
   for (uint32_t rr = d.k; rr-- > 0;) {
     uint8_t* T = rtab + ((size_t)rr * 15 * B + p) * 64;
@@ -310,26 +379,41 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
 }
 
 // one IPP round of mkChallenges: acc <- x^2 L + x^-2 R + acc  (Verifier.hs:47-50)
+template <bool BATCH_INV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_round(VDims d, uint32_t round,
                                               const uint8_t* __restrict__ xk /*[B][32] canonical*/,
                                               u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
                                               const uint8_t* __restrict__ rtab, uint8_t* __restrict__ acc_aff,
-                                              uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
+                                              uint8_t* __restrict__ host_out /*pinned host copy, or null*/,
+                                              uint8_t* __restrict__ host_txt /*pinned [B][2][80] decimal text, or null*/) {
+  __shared__ uint32_t lds[256 * 2 * DEC_REC_WORDS];
   __builtin_amdgcn_s_setprio(3);  // on the host's critical path, like k_stage1_tail
+  __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.B) return;
-  size_t B = d.B;
-  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
-  u256 xinv = Fr::inv(x);
-  stm(xk_m, (size_t)round * B + p, x);
-  stm(xkinv_m, (size_t)round * B + p, xinv);
-  const uint8_t* T = rtab + ((size_t)round * 15 * B + p) * 64;
-  xyzz acc = glv_pair_multiexp_tab(Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv)),
-                                   [&](int e) { return ld_affine(T + (size_t)(e - 1) * B * 64); });
-  acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
-  affine out = xyzz_to_affine(acc);
-  st_affine(acc_aff + (size_t)p * 64, out);
-  if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  const bool live = p < d.B;
+  const size_t B = d.B;
+  u256 x = Fr::one();
+  if (live) x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
+  // x^-1 and, below, the affine form of the result: one inversion per workgroup each (batchinv.h)
+  u256 xinv = BATCH_INV ? block_batch_inverse<FrInvOps>(x, inv_lds) : Fr::inv(x);
+  xyzz acc = xyzz_inf();
+  if (live) {
+    stm(xk_m, (size_t)round * B + p, x);
+    stm(xkinv_m, (size_t)round * B + p, xinv);
+    const uint8_t* T = rtab + ((size_t)round * 15 * B + p) * 64;
+    acc = glv_pair_multiexp_tab(Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv)),
+                                [&](int e) { return ld_affine(T + (size_t)(e - 1) * B * 64); });
+    acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
+  }
+  const u256 zzz = live ? acc.ZZZ : u256_one();
+  u256 zi = BATCH_INV ? block_batch_inverse<FqInvOps>(zzz, inv_lds) : fq_inv(zzz);
+  affine out = affine_inf();
+  if (live) {
+    out = xyzz_to_affine_with_inv(acc, zi);
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  }
+  if (host_txt) block_store_point_text(lds, out, host_txt, d.B);
 }
 
 // thread per proof: s0 = prod_k x_k^-1  (mkOtherExponents, Verifier.hs:59)
@@ -479,13 +563,45 @@ static inline void launch_tcheck(bp_vbatch* vb, hipStream_t strm) {
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
   bp_ctx* ctx = vb->ctx;
   size_t B = vb->d.B;
+  if (vb->tab_pending) {  // tables of the previous proofs
+    BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->tab_pending = false;
+  }
   BP_TRY(hipMemcpyAsync(vb->sc, scalars, 5 * B * 32, hipMemcpyHostToDevice, vb->stream));
   BP_TRY(hipMemcpyAsync(vb->pts, points, (size_t)vb->npts * B * 64, hipMemcpyHostToDevice, vb->stream));
   vb->stage = 1;
   return BP_OK;
 }
 
-int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment) {
+// Work of a pass that needs the proof's points only, on the side stream: the decimal text of L_r, R_r for the host's
+// round transcripts (lr_text: pinned [2k][B][2][80], or null) and the rounds' joint tables.  The batch job calls this
+// for every chunk when a pass starts, so the GPU is busy while the host hashes the first challenges; otherwise
+// vbatch_begin_async does.  Joined by the host before round 0.
+int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->stage < 1) {
+    ctx->err = "bp_vbatch prepare before bp_vbatch_load";
+    return BP_ERR_STATE;
+  }
+  VDims d = vb->d;
+  size_t B = d.B;
+  if (d.k == 0 || vb->tab_pending) return BP_OK;
+  if (vb->t_pending) {  // a previous pass's side work
+    BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->t_pending = false;
+  }
+  if (lr_text && vb->direct_host) {
+    size_t cnt = (size_t)2 * d.k * B * 2;
+    hipLaunchKernelGGL(k_dec_numbers, VB_GRID_ON(cnt, vb->aux), vb->pts + (size_t)VP_L0 * B * 64, (uint32_t)cnt, lr_text);
+  }
+  hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
+  BP_TRY(hipGetLastError());
+  vb->tab_pending = true;
+  return BP_OK;
+}
+
+int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment, uint8_t* out_text,
+                       uint8_t* lr_text) {
   bp_ctx* ctx = vb->ctx;
   if (vb->stage < 1) {
     ctx->err = "bp_vbatch_begin before bp_vbatch_load";
@@ -493,10 +609,13 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   }
   VDims d = vb->d;
   size_t B = d.B;
-  if (vb->t_pending || vb->tab_pending) {  // begun again before the previous pass finished: its side work still reads the constants
+  if (vb->t_pending) {  // begun again before the previous pass finished: its side work still reads the constants
     BP_TRY(hipStreamSynchronize(vb->aux));
     vb->t_pending = false;
-    vb->tab_pending = false;
+  }
+  {
+    int rc = vbatch_prepare_async(vb, lr_text);  // no-op when the caller has prepared this pass already
+    if (rc != BP_OK) return rc;
   }
   // pinned caller buffers are read by the kernel itself (one 32-byte read per proof and challenge over the
   // host link): no copy command enters the queue
@@ -504,11 +623,6 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   if (!vb->direct_host) {
     BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
     chal = vb->chal;
-  }
-  if (d.k > 0) {
-    // the rounds' joint tables need the proof's points only: side stream, joined by the host before round 0
-    hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
-    vb->tab_pending = true;
   }
   hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow);
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
@@ -520,7 +634,8 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   // other (measured: benchmarks/concurrency_test3.hip); with pinned outputs the kernel stores its
   // result to host memory itself.
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
-  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct);
+  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
+                     vb->direct_host ? out_text : nullptr);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
@@ -528,7 +643,7 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   return BP_OK;
 }
 
-int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment) {
+int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment, uint8_t* out_text) {
   bp_ctx* ctx = vb->ctx;
   if (vb->stage != (int)(2 + round) || round >= vb->d.k) {
     ctx->err = "bp_vbatch_round out of order";
@@ -553,7 +668,15 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
     xin = vb->xk;
   }
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
-  hipLaunchKernelGGL(k_round, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct);
+  // The two inversions of a round are per lane: the kernel is a latency chain the host waits for, and sharing
+  // them across the workgroup (batchinv.h) lengthens it (1.58 -> 1.71 ms).  BP_ROUND_BATCHINV=1 selects the shared form.
+  static const bool round_batch = getenv("BP_ROUND_BATCHINV") && atoi(getenv("BP_ROUND_BATCHINV")) != 0;
+  if (round_batch)
+    hipLaunchKernelGGL(k_round<true>, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct,
+                       vb->direct_host ? out_text : nullptr);
+  else
+    hipLaunchKernelGGL(k_round<false>, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct,
+                       vb->direct_host ? out_text : nullptr);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage++;
@@ -756,7 +879,7 @@ int bp_vbatch_begin(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commi
   bp_ctx* ctx = vb->ctx;
   BP_REQUIRE(challenges && out_commitment, "null pointer");
   BP_TRY(hipSetDevice(ctx->device));
-  int rc = vbatch_begin_async(vb, challenges, out_commitment);
+  int rc = vbatch_begin_async(vb, challenges, out_commitment, nullptr, nullptr);
   return rc != BP_OK ? rc : vbatch_wait(vb);
 }
 
@@ -765,7 +888,7 @@ int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* ou
   bp_ctx* ctx = vb->ctx;
   BP_REQUIRE(x && out_commitment, "null pointer");
   BP_TRY(hipSetDevice(ctx->device));
-  int rc = vbatch_round_async(vb, round, x, out_commitment);
+  int rc = vbatch_round_async(vb, round, x, out_commitment, nullptr);
   return rc != BP_OK ? rc : vbatch_wait(vb);
 }
 

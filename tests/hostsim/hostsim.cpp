@@ -145,6 +145,14 @@ extern "C" void hs_glv_pair_tab(const uint8_t* ks, const uint8_t* ps, uint8_t* o
   sta(out, xyzz_to_affine(r));
 }
 
+// ---- device decimal formatter (dec.h): 80-byte record of a 32-byte LE integer ----
+#include "../../bulletproofs_amd/csrc/dec.h"
+extern "C" void hs_dec_record(const uint8_t* le, uint8_t* rec80) {
+  uint32_t w[DEC_REC_WORDS];
+  u256_to_dec_record(ld(le), w);
+  memcpy(rec80, w, DEC_REC);
+}
+
 // ---- host transcript primitives (transcript.h): paired SHA-256 and the decimal writer ----
 #include "../../bulletproofs_amd/csrc/transcript.h"
 // digests of two messages through the interleaved path (skip_a / skip_b full leading blocks are absorbed
@@ -158,3 +166,10 @@ extern "C" void hs_sha256_pair(uint8_t* a, size_t la, size_t skip_a, uint8_t* b,
   sha256_resume_inplace_x2(ma, a, la, outa, mb, b, lb, outb);
 }
 extern "C" size_t hs_u256_to_dec(const uint8_t* le, char* out) { return bp::host::u256_to_dec(le, out); }
+// show text of a point / scalar from dec.h records (x record, y record), as the host appends it to a transcript
+extern "C" size_t hs_show_point_rec(int style, const uint8_t* recs, char* out) {
+  return bp::host::show_point_rec((bp::host::ShowStyle)style, recs, recs + 80, out);
+}
+extern "C" size_t hs_show_point(int style, const uint8_t* pt, char* out) {
+  return bp::host::show_point((bp::host::ShowStyle)style, pt, out);
+}

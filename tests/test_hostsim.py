@@ -119,6 +119,34 @@ def test_group_law_total(hs):
     assert hs.hs_on_curve(pb(G)) == 1 and hs.hs_on_curve(pb((5, 7))) == 0 and hs.hs_on_curve(pb(None)) == 1
 
 
+def test_device_decimal_records(hs):
+    """dec.h (the formatter the kernels use for the transcript's `show` text): the 80-byte record of a 256-bit
+    integer carries str(v) right-aligned and its length, for edge values and random ones; a point shown from
+    two records equals the host formatter's text in both `show` styles."""
+    rng = random.Random(123)
+    vals = [0, 1, 9, 10, 10**9 - 1, 10**9, 10**18, 2**32 - 1, 2**32, 2**64, 10**77 - 1, 10**77, P - 1, P, R, 2**256 - 1]
+    vals += [10**e for e in range(0, 78)] + [10**e - 1 for e in range(1, 78)]
+    vals += [rng.randrange(2**rng.randrange(1, 257)) for _ in range(20000)]
+    rec = ctypes.create_string_buffer(80)
+    for v in vals:
+        hs.hs_dec_record(b(v), rec)
+        n = rec.raw[0]
+        assert rec.raw[80 - n:80].decode() == str(v), v
+    out1, out2 = ctypes.create_string_buffer(256), ctypes.create_string_buffer(256)
+    hs.hs_show_point_rec.restype = ctypes.c_size_t
+    hs.hs_show_point.restype = ctypes.c_size_t
+    pts = [None, o.GEN, (1, 0), (0, 1)] + [(rng.randrange(P), rng.randrange(P)) for _ in range(200)]
+    for style in (0, 1):
+        for pt in pts:
+            raw = pb(pt) if pt is not None else bytes(64)
+            rx, ry = ctypes.create_string_buffer(80), ctypes.create_string_buffer(80)
+            hs.hs_dec_record(raw[:32], rx)
+            hs.hs_dec_record(raw[32:], ry)
+            n1 = hs.hs_show_point_rec(style, rx.raw + ry.raw, out1)
+            n2 = hs.hs_show_point(style, raw, out2)
+            assert out1.raw[:n1] == out2.raw[:n2]
+
+
 LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
 
 
