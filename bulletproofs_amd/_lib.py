@@ -54,6 +54,7 @@ SYMBOLS = {
     "bp_msm": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
+    "bp_show_numbers": (_int, [_vp, _u8p, _sz, _u8p]),
     "bp_ctx_set_generators": (_int, [_vp, _u8p, _u8p, _u8p, ctypes.c_uint32]),
     "bp_vbatch_create": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "bp_vbatch_destroy": (None, [_vp]),
@@ -258,6 +259,14 @@ class Engine:
         out = ctypes.create_string_buffer(32 * n)
         self._check(self.lib.bp_field_op(self.h, field, op, enc_scalars(a), enc_scalars(b), n, out), "bp_field_op")
         return dec_scalars(out.raw, n)
+
+    def show_numbers(self, values):
+        """Decimal text of 256-bit integers as the verifier's kernels format it for the host transcript."""
+        n = len(values)
+        out = ctypes.create_string_buffer(80 * n)
+        self._check(self.lib.bp_show_numbers(self.h, enc_scalars(values), n, out), "bp_show_numbers")
+        raw = out.raw
+        return [raw[80 * i + 80 - raw[80 * i]:80 * i + 80].decode() for i in range(n)]
 
     # -- generators and the batch verifier state machine ---------------------------------
     def set_generators(self, gs, hs, h):

@@ -3,6 +3,7 @@
 // Reference call sites: /root/reference/Bulletproofs/Utils.hs:72-73,84-85,
 // RangeProof/Internal.hs:183-205, InnerProductProof/Prover.hs:81-92, test/Test/Field.hs.
 #include "engine.h"
+#include "verify.h"
 #include "devio.h"
 
 namespace bp {
@@ -220,6 +221,19 @@ int bp_field_op(bp_ctx* ctx, int field, int op, const uint8_t* a, const uint8_t*
                         BP_TRY(hipGetLastError());
                         return BP_OK;
                       });
+}
+
+int bp_show_numbers(bp_ctx* ctx, const uint8_t* numbers, size_t n, uint8_t* records) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(n == 0 || (numbers && records), "null pointer");
+  BP_CHECK_N(n);
+  if (n == 0) return BP_OK;
+  BP_TRY(hipSetDevice(ctx->device));
+  return with_staging(ctx, {{numbers, n * 32}}, records, n * 80, [&](std::vector<const uint8_t*>& d, uint8_t* dout) {
+    hipLaunchKernelGGL(k_dec_numbers, GRID(n), d[0], (uint32_t)n, dout);
+    BP_TRY(hipGetLastError());
+    return BP_OK;
+  });
 }
 
 int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out) {

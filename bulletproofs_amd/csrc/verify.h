@@ -69,6 +69,8 @@ struct bp_vbatch {
 };
 
 namespace bp {
+// record i (dec.h, 80 bytes) = decimal text of the 32-byte little-endian integer i of src; dst may be pinned host memory
+__global__ void k_dec_numbers(const uint8_t* __restrict__ src, uint32_t count, uint8_t* __restrict__ dst);
 // Asynchronous forms (enqueue on vb->stream, no synchronisation); the host buffers
 // must stay valid until the stream has been synchronised (use pinned memory for overlap).
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points);

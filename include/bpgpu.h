@@ -276,6 +276,15 @@ int bp_rangeproof_show(const uint8_t* scalars, const uint8_t* points, uint32_t k
  */
 int bp_field_op(bp_ctx* ctx, int field, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
 
+/* ---- decimal `show` digits on the device (self-test hook of the verifier's text path) ----
+ * The transcript hashes `show` text of points and scalars (`pointToBS = show`, Utils.hs:32-33,145-174).  The
+ * batch verifier's kernels format the numbers they produce (and the proof's L_r, R_r) themselves and hand
+ * the host 80-byte records: byte 0 = digit count n (1..78), ASCII digits right-aligned in [80 - n, 80).
+ * This entry point runs the same kernel on n 32-byte little-endian integers (host pointers) and returns
+ * their records, so the tests can compare them with the oracle's decimal text.  Hashing stays on the host.
+ */
+int bp_show_numbers(bp_ctx* ctx, const uint8_t* numbers, size_t n, uint8_t* records);
+
 #ifdef __cplusplus
 }
 #endif

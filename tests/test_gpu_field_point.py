@@ -122,3 +122,14 @@ def test_add_two_mul_p(engine):
     xs = [rng.randrange(R) for _ in range(8)]
     rs = [rng.randrange(R) for _ in range(8)]
     assert engine.add_two_mul_p(xs, [o.GEN] * 8, rs, [o.h()] * 8) == [o.commit(a, c) for a, c in zip(xs, rs)]
+
+
+def test_device_decimal_text(engine):
+    """The kernels' `show` digits (dec.h, k_dec_numbers: what the host transcript concatenates) equal str()
+    for edge values, every power of ten and random integers, across several workgroups."""
+    rng = random.Random(2024)
+    vals = [0, 1, 9, 10, 2**32 - 1, 2**32, 2**64, 10**77 - 1, 10**77, o.P - 1, o.P, o.R, 2**256 - 1]
+    vals += [10**e for e in range(78)] + [10**e - 1 for e in range(1, 78)]
+    vals += [rng.randrange(2**rng.randrange(1, 257)) for _ in range(3000)]
+    assert engine.show_numbers(vals) == [str(v) for v in vals]
+    assert engine.show_numbers([]) == []
