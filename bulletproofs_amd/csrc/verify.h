@@ -50,7 +50,7 @@ struct bp_vbatch {
   bool begun_complete;    // the begin stage has been waited for (its constants are complete)
   // device
   uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
-  bp::u256 *cst, *ypowinv, *zpow, *xk_m, *xkinv_m;
+  bp::u256 *cst, *ypowinv, *zpow, *xk_m /* x_k^2 */, *xkinv_m, *stab /* half-tables of the s-vector */;
   uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
   bp::xyzz *acc1, *acc2, *vtab, *vtab2;  // vtab2: joint tables of the t-check (runs beside the rounds)
   // joint tables of the rounds: affine entries, and the XYZZ composites / running products they are normalised from

@@ -26,7 +26,7 @@
 namespace bp {
 
 // ---- per-proof constants (Montgomery form), cst[c * B + p] -----------------------
-enum { C_Y = 0, C_Z, C_X, C_U, C_YINV, C_X2, C_DELTA, C_S0, C_COUNT };
+enum { C_Y = 0, C_Z, C_X, C_U, C_YINV, C_X2, C_DELTA, C_S0, C_ZP /* z, plain form */, C_COUNT };
 
 __device__ __forceinline__ u256 ldm(const u256* a, size_t idx) { return ld_u256(a + idx); }
 __device__ __forceinline__ void stm(u256* a, size_t idx, const u256& v) { st_u256(a + idx, v); }
@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restri
   if (p < d.B) y = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)0 * B + p) * 32)));
   u256 yinv = block_batch_inverse<FrInvOps>(y, inv_lds);  // one inversion per workgroup (batchinv.h)
   if (p >= d.B) return;
-  u256 z = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)1 * B + p) * 32)));
+  u256 zp = Fr::reduce_once(ld_u256(chal + ((size_t)1 * B + p) * 32));
+  u256 z = Fr::to_mont(zp);
+  stm(cst, C_ZP * B + p, zp);
   u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)2 * B + p) * 32)));
   u256 u = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)3 * B + p) * 32)));
   stm(cst, C_Y * B + p, y);
@@ -108,18 +110,19 @@ __global__ void __launch_bounds__(256) k_vprep1(VDims d, const uint8_t* __restri
   size_t B = d.B;
   if (t >= (size_t)d.nm * B) return;
   uint32_t i = (uint32_t)(t / B), p = (uint32_t)(t % B);
-  u256 z = ldm(cst, C_Z * B + p);
+  u256 zp = ldm(cst, C_ZP * B + p);  // plain form
   uint32_t j = i / d.n, k = i % d.n;
   u256 two_k = u256_zero();
   two_k.v[k >> 5] = 1u << (k & 31);
-  u256 c = Fr::mul(Fr::mul(ldm(zpow, (size_t)(j + 2) * B + p), Fr::to_mont(Fr::reduce_once(two_k))),
-                   ldm(ypowinv, (size_t)i * B + p));
-  c = Fr::add(c, z);
-  put_digits(dig, i, d, p, Fr::from_mont(c));
+  // a Montgomery product of a plain and a Montgomery-form operand is the plain product: two multiplications
+  // give the canonical scalar directly (no to_mont / from_mont)
+  u256 c = Fr::mul(Fr::mul(Fr::reduce_once(two_k), ldm(zpow, (size_t)(j + 2) * B + p)), ldm(ypowinv, (size_t)i * B + p));
+  c = Fr::add(c, zp);
+  put_digits(dig, i, d, p, c);
   if (i == 0) {
     u256 mu = Fr::reduce_once(ld_u256(sc + ((size_t)1 * B + p) * 32));
     u256 tt = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)2 * B + p) * 32)));
-    put_digits(dig, d.nm + 0, d, p, Fr::from_mont(Fr::neg(z)));                         // -z  * GS
+    put_digits(dig, d.nm + 0, d, p, Fr::neg(zp));                                       // -z  * GS
     put_digits(dig, d.nm + 1, d, p, Fr::neg(mu));                                       // -mu * H  (canonical neg)
     put_digits(dig, d.nm + 2, d, p, Fr::from_mont(Fr::mul(tt, ldm(cst, C_U * B + p))));  // t*u * G
   }
@@ -382,7 +385,7 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
 template <bool BATCH_INV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_round(VDims d, uint32_t round,
                                               const uint8_t* __restrict__ xk /*[B][32] canonical*/,
-                                              u256* __restrict__ xk_m /*[k][B]*/, u256* __restrict__ xkinv_m,
+                                              u256* __restrict__ xk_m /*[k][B]: x_k^2 */, u256* __restrict__ xkinv_m,
                                               const uint8_t* __restrict__ rtab, uint8_t* __restrict__ acc_aff,
                                               uint8_t* __restrict__ host_out /*pinned host copy, or null*/,
                                               uint8_t* __restrict__ host_txt /*pinned [B][2][80] decimal text, or null*/) {
@@ -398,10 +401,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   u256 xinv = BATCH_INV ? block_batch_inverse<FrInvOps>(x, inv_lds) : Fr::inv(x);
   xyzz acc = xyzz_inf();
   if (live) {
-    stm(xk_m, (size_t)round * B + p, x);
+    const u256 x2 = Fr::sqr(x);
+    stm(xk_m, (size_t)round * B + p, x2);  // mkOtherExponents needs the squares only (Verifier.hs:66-71)
     stm(xkinv_m, (size_t)round * B + p, xinv);
     const uint8_t* T = rtab + ((size_t)round * 15 * B + p) * 64;
-    acc = glv_pair_multiexp_tab(Fr::from_mont(Fr::sqr(x)), Fr::from_mont(Fr::sqr(xinv)),
+    acc = glv_pair_multiexp_tab(Fr::from_mont(x2), Fr::from_mont(Fr::sqr(xinv)),
                                 [&](int e) { return ld_affine(T + (size_t)(e - 1) * B * 64); });
     acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
   }
@@ -416,39 +420,57 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   if (host_txt) block_store_point_text(lds, out, host_txt, d.B);
 }
 
-// thread per proof: s0 = prod_k x_k^-1  (mkOtherExponents, Verifier.hs:59)
-__global__ void __launch_bounds__(256) k_vprep3a(VDims d, const u256* __restrict__ xkinv_m, u256* __restrict__ cst) {
+// mkOtherExponents (Verifier.hs:55-73): s_i = s0 * prod_{bit j of i} x_{k-1-j}^2, s0 = prod_k x_k^-1 (challenges are
+// listed last round first, so bit 0 pairs with the LAST round).  The index is split into its low kl = k/2 bits
+// and the rest: s_i = lo[i & (2^kl - 1)] * hi[i >> kl], with s0 folded into lo.  Thread per proof: both
+// half-tables by one multiplication per entry, stab[e * B + p], lo entries first.
+__device__ __forceinline__ uint32_t vsplit_lo_bits(uint32_t k) { return k >> 1; }
+
+__global__ void __launch_bounds__(256) k_vprep3a(VDims d, const u256* __restrict__ xk2_m, const u256* __restrict__ xkinv_m,
+                                                u256* __restrict__ cst, u256* __restrict__ stab) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
   u256 s0 = Fr::one();
   for (uint32_t r = 0; r < d.k; r++) s0 = Fr::mul(s0, ldm(xkinv_m, (size_t)r * B + p));
   stm(cst, C_S0 * B + p, s0);
+  const uint32_t kl = vsplit_lo_bits(d.k), kh = d.k - kl, nlo = 1u << kl, nhi = 1u << kh;
+  stm(stab, (size_t)0 * B + p, s0);
+  for (uint32_t e = 1; e < nlo; e++) {
+    uint32_t j = (uint32_t)__builtin_ctz(e);
+    stm(stab, (size_t)e * B + p,
+        Fr::mul(ldm(stab, (size_t)(e & (e - 1)) * B + p), ldm(xk2_m, (size_t)(d.k - 1 - j) * B + p)));
+  }
+  stm(stab, (size_t)nlo * B + p, Fr::one());
+  for (uint32_t e = 1; e < nhi; e++) {
+    uint32_t j = (uint32_t)__builtin_ctz(e);
+    stm(stab, (size_t)(nlo + e) * B + p,
+        Fr::mul(ldm(stab, (size_t)(nlo + (e & (e - 1))) * B + p), ldm(xk2_m, (size_t)(d.k - 1 - (kl + j)) * B + p)));
+  }
 }
 
-// thread per (i, p): s_i = s0 * prod_{bit j of i} x_{k-1-j}^2   (Verifier.hs:55-73: challenges are
-// listed last round first, so bit 0 pairs with the LAST round); emits
+// thread per (i, p): emits
 //   term i            (base G_i):        l * s_i
 //   term nm + (nm-1-i) (base H_{nm-1-i}): r * s_i * y^-(nm-1-i)        (reverse otherExponents, :38)
-// and for i == 0 the remaining single terms and the variable-base scalars of E2.
+// and for i == 0 the remaining single term.  l and r enter in plain form: the Montgomery product of a plain and a
+// Montgomery-form operand is the plain product, so the scalars come out canonical without conversions.
 __global__ void __launch_bounds__(256) k_vprep3(VDims d, const uint8_t* __restrict__ sc, const u256* __restrict__ cst,
-                                               const u256* __restrict__ ypowinv, const u256* __restrict__ xk_m,
+                                               const u256* __restrict__ ypowinv, const u256* __restrict__ stab,
                                                uint32_t* __restrict__ dig_a) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t B = d.B;
   if (t >= (size_t)d.nm * B) return;
   uint32_t i = (uint32_t)(t / B), p = (uint32_t)(t % B);
-  u256 s = ldm(cst, C_S0 * B + p);
-  for (uint32_t j = 0; j < d.k; j++)
-    if ((i >> j) & 1u) s = Fr::mul(s, Fr::sqr(ldm(xk_m, (size_t)(d.k - 1 - j) * B + p)));
-  u256 l = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)3 * B + p) * 32)));
-  u256 r = Fr::to_mont(Fr::reduce_once(ld_u256(sc + ((size_t)4 * B + p) * 32)));
-  put_digits(dig_a, i, d, p, Fr::from_mont(Fr::mul(l, s)));
+  const uint32_t kl = vsplit_lo_bits(d.k), nlo = 1u << kl;
+  u256 s = Fr::mul(ldm(stab, (size_t)(i & (nlo - 1)) * B + p), ldm(stab, (size_t)(nlo + (i >> kl)) * B + p));
+  u256 lp = Fr::reduce_once(ld_u256(sc + ((size_t)3 * B + p) * 32));
+  u256 rp = Fr::reduce_once(ld_u256(sc + ((size_t)4 * B + p) * 32));
+  put_digits(dig_a, i, d, p, Fr::mul(lp, s));
   uint32_t hi = d.nm - 1 - i;
-  put_digits(dig_a, d.nm + hi, d, p, Fr::from_mont(Fr::mul(Fr::mul(r, s), ldm(ypowinv, (size_t)hi * B + p))));
+  put_digits(dig_a, d.nm + hi, d, p, Fr::mul(Fr::mul(rp, s), ldm(ypowinv, (size_t)hi * B + p)));
   if (i == 0) {
     u256 u = ldm(cst, C_U * B + p);
-    put_digits(dig_a, 2 * d.nm, d, p, Fr::from_mont(Fr::mul(Fr::mul(l, r), u)));  // (l r u) G
+    put_digits(dig_a, 2 * d.nm, d, p, Fr::mul(Fr::mul(lp, Fr::to_mont(rp)), u));  // (l r u) G
   }
 }
 
@@ -691,8 +713,8 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
   }
   VDims d = vb->d;
   size_t B = d.B;
-  hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xkinv_m, vb->cst);
-  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->xk_m, vb->dig3a);
+  hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xk_m, vb->xkinv_m, vb->cst, vb->stab);
+  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->stab, vb->dig3a);
   uint32_t lpp = vbatch_lpp(d.B);
   prof_begin(vb, 1, vb->nt3a);
   launch_fixed(vb, B * lpp, vb->nt3a, lpp, vb->dig3a, vb->tb3a, vb->acc1);
@@ -783,6 +805,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->zpow = c.take<u256>((size_t)(m + 3) * B);
     vb->xk_m = c.take<u256>((size_t)(d.k ? d.k : 1) * B);
     vb->xkinv_m = c.take<u256>((size_t)(d.k ? d.k : 1) * B);
+    vb->stab = c.take<u256>(((size_t)1 << (d.k >> 1)) * B + ((size_t)1 << (d.k - (d.k >> 1))) * B);
     vb->dig1 = c.take<uint32_t>((size_t)vb->nt1 * DW * B);
     vb->dig3a = c.take<uint32_t>((size_t)vb->nt3a * DW * B);
     vb->dig3b = c.take<uint32_t>((size_t)vb->nt3b * DW * B);
