@@ -79,9 +79,34 @@ def cpu_baseline(sc, pts, n_bits, sample, gpu_verdicts):
     cpu = np.frombuffer(out.raw, dtype=np.uint8)
     if not (cpu == gpu_verdicts[:sample]).all():
         raise SystemExit("PARITY FAILURE: GPU verdicts differ from the CPU restatement on the sample")
-    return dict(value=sample / dt, unit="verifies/s", cores=1, kind="port",
-                sample="first %d proofs of the same batch, oracle/bp_ref.c (C restatement of the reference's "
-                       "algorithm; GHC is not available), verdicts identical to the GPU's" % sample)
+    res = dict(value=sample / dt, unit="verifies/s", cores=1, kind="port",
+               sample="first %d proofs of the same batch, oracle/bp_ref.c (C restatement of the reference's "
+                      "algorithm; GHC is not available), verdicts identical to the GPU's" % sample)
+    # the same port over the box's CPU share (independent proofs, one slice per thread; the reference itself is
+    # single-threaded): a second, short figure next to the one-core baseline
+    cores = min(16, os.cpu_count() or 1)
+    per = max(1, min(12, sample // cores))
+    if cores > 1:
+        import threading
+        outs = [ctypes.create_string_buffer(per) for _ in range(cores)]
+
+        def work(t):
+            L.bpref_verify_batch(n_bits, 1, ctypes.c_size_t(B), sc.ctypes.data_as(ctypes.c_char_p),
+                                 pts.ctypes.data_as(ctypes.c_char_p), ctypes.c_size_t(t * per), ctypes.c_size_t(per),
+                                 outs[t])
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dtm = time.perf_counter() - t0
+        multi = np.concatenate([np.frombuffer(o_.raw, dtype=np.uint8) for o_ in outs])
+        if not (multi == gpu_verdicts[:cores * per]).all():
+            raise SystemExit("PARITY FAILURE: GPU verdicts differ from the threaded CPU restatement")
+        res["multi"] = dict(value=cores * per / dtm, unit="verifies/s", cores=cores,
+                            sample="%d threads x %d proofs of the same batch" % (cores, per))
+    return res
 
 
 def msm_probe(eng, logn, iters):

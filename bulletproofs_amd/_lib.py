@@ -55,6 +55,8 @@ SYMBOLS = {
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
     "bp_show_numbers": (_int, [_vp, _u8p, _sz, _u8p]),
+    "bp_generators_save": (_int, [_vp, ctypes.c_char_p]),
+    "bp_generators_load": (_int, [_vp, ctypes.c_char_p]),
     "bp_ctx_set_generators": (_int, [_vp, _u8p, _u8p, _u8p, ctypes.c_uint32]),
     "bp_vbatch_create": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "bp_vbatch_destroy": (None, [_vp]),
@@ -285,6 +287,14 @@ class Engine:
         h1 = ctypes.create_string_buffer(64)
         self._check(self.lib.bp_generators_derive(self.h, n, g, hh, h1), "bp_generators_derive")
         return dec_points(g.raw, n), dec_points(hh.raw, n), dec_point(h1.raw)
+
+    def save_generators(self, path):
+        """Write the installed `h`, `gs`, `hs` to a file (bp_generators_save)."""
+        self._check(self.lib.bp_generators_save(self.h, os.fsencode(path)), "bp_generators_save")
+
+    def load_generators(self, path):
+        """Install generators from a file written by save_generators (checked: checksum, on-curve)."""
+        self._check(self.lib.bp_generators_load(self.h, os.fsencode(path)), "bp_generators_load")
 
     def verify_batch(self, n_bits, m, batch, scalars, points):
         """`map (verifyProof upperBound)` over a batch (MultiRangeProof/Verifier.hs:19-39)."""

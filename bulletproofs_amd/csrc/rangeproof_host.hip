@@ -7,12 +7,15 @@
 // GHC exists in this image).  Hashing is multi-threaded over independent proofs
 // and ping-pongs with the GPU: the batch is cut into chunks, and while the GPU
 // runs one chunk's round the host hashes the other chunk's transcript.
+#include <stdio.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
+#include <vector>
 
 #include "engine.h"
 #include "transcript.h"
@@ -518,6 +521,95 @@ int bp_generators_derive(bp_ctx* ctx, uint32_t n_gens, uint8_t* gs_out, uint8_t*
   if (hs_out) memcpy(hs_out, out.data() + (size_t)n_gens * 64, (size_t)n_gens * 64);
   if (h_out) memcpy(h_out, hpt, 64);
   return bp_ctx_set_generators(ctx, out.data(), out.data() + (size_t)n_gens * 64, hpt, n_gens);
+}
+
+// The generator CAFs as a file: `h`, `take n gs`, `take n hs` written once and installed by later
+// processes without the hashing and the 2n scalar multiplications of bp_generators_derive.
+// Layout: "BPGENS01", u32 n_gens, u32 show style, u32 sqrt branch, u32 0, gs (n x 64 B), hs (n x 64 B), h (64 B),
+// SHA-256 of everything before it.  The style / branch the table was derived under are recorded because h, and with it
+// every hs_i, depends on them (Utils.hs:38-47); loading sets the context to the recorded values.
+int bp_generators_save(bp_ctx* ctx, const char* path) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(path, "null pointer");
+  if (ctx->n_gens == 0) {
+    ctx->err = "generators not set (bp_generators_derive)";
+    return BP_ERR_STATE;
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  const size_t n = ctx->n_gens, body = 24 + (2 * n + 1) * 64;
+  std::vector<uint8_t> buf(body + 32 + 72);
+  memcpy(buf.data(), "BPGENS01", 8);
+  uint32_t hdr[4] = {(uint32_t)n, (uint32_t)ctx->show_style, (uint32_t)ctx->sqrt_branch, 0u};
+  memcpy(buf.data() + 8, hdr, 16);
+  // device layout of the bases: gs, hs, G, h (gens.hip)
+  BP_TRY(hipMemcpy(buf.data() + 24, ctx->d_bases, 2 * n * 64, hipMemcpyDeviceToHost));
+  BP_TRY(hipMemcpy(buf.data() + 24 + 2 * n * 64, ctx->d_bases + (2 * n + 1) * 64, 64, hipMemcpyDeviceToHost));
+  uint8_t dg[32];
+  std::vector<uint8_t> tmp(buf.begin(), buf.begin() + body);
+  tmp.resize(body + 72);
+  sha256_inplace(tmp.data(), body, dg);
+  memcpy(buf.data() + body, dg, 32);
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    ctx->err = std::string("cannot open ") + path + " for writing";
+    return BP_ERR_ARG;
+  }
+  bool ok = fwrite(buf.data(), 1, body + 32, f) == body + 32;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) {
+    ctx->err = std::string("short write to ") + path;
+    return BP_ERR_STATE;
+  }
+  return BP_OK;
+}
+
+int bp_generators_load(bp_ctx* ctx, const char* path) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(path, "null pointer");
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    ctx->err = std::string("cannot open ") + path;
+    return BP_ERR_ARG;
+  }
+  uint8_t head[24];
+  uint32_t hdr[4] = {0, 0, 0, 0};
+  bool ok = fread(head, 1, 24, f) == 24 && memcmp(head, "BPGENS01", 8) == 0;
+  if (ok) memcpy(hdr, head + 8, 16);
+  const size_t n = hdr[0];
+  ok = ok && n >= 1 && n <= 8192 && (n & (n - 1)) == 0 && hdr[1] <= 1 && hdr[2] <= 1;
+  std::vector<uint8_t> buf;
+  const size_t body = 24 + (2 * n + 1) * 64;
+  if (ok) {
+    buf.resize(body + 72);
+    memcpy(buf.data(), head, 24);
+    uint8_t want[32], got[32], extra;
+    ok = fread(buf.data() + 24, 1, body - 24, f) == body - 24 && fread(want, 1, 32, f) == 32 && fread(&extra, 1, 1, f) == 0;
+    if (ok) {
+      std::vector<uint8_t> tmp(buf);
+      sha256_inplace(tmp.data(), body, got);
+      ok = memcmp(want, got, 32) == 0;
+    }
+  }
+  fclose(f);
+  if (!ok) {
+    ctx->err = std::string(path) + " is not a generator table (bad magic, size or checksum)";
+    return BP_ERR_ARG;
+  }
+  // every entry must be a finite curve point: the table replaces group elements the reference computes itself
+  std::vector<uint8_t> oc(2 * n + 1);
+  int rc = bp_point_on_curve(ctx, buf.data() + 24, 2 * n + 1, oc.data());
+  if (rc != BP_OK) return rc;
+  for (size_t i = 0; i < 2 * n + 1; i++) {
+    bool inf = true;
+    for (int b = 0; b < 64; b++) inf = inf && buf[24 + i * 64 + b] == 0;
+    if (!oc[i] || inf) {
+      ctx->err = std::string(path) + ": entry is not a finite point of the curve";
+      return BP_ERR_ARG;
+    }
+  }
+  ctx->show_style = (int)hdr[1];
+  ctx->sqrt_branch = (int)hdr[2];
+  return bp_ctx_set_generators(ctx, buf.data() + 24, buf.data() + 24 + n * 64, buf.data() + 24 + 2 * n * 64, (uint32_t)n);
 }
 
 }  // extern "C"

@@ -180,6 +180,13 @@ int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts);
 int bp_ctx_set_show_style(bp_ctx* ctx, int style);
 int bp_ctx_set_sqrt_branch(bp_ctx* ctx, int branch);
 int bp_generators_derive(bp_ctx* ctx, uint32_t n_gens, uint8_t* gs_out, uint8_t* hs_out, uint8_t* h_out);
+/* The evaluated CAFs `h`, `take n gs`, `take n hs` (Utils.hs:14-25) as a file: save writes the generators the
+ * context holds (with the show style / sqrt branch they were derived under and a SHA-256 checksum); load checks
+ * the file (magic, size, checksum, every entry a finite curve point), sets the context's style / branch to the
+ * recorded ones and installs the generators like bp_ctx_set_generators.  What a long-lived Haskell process gets from
+ * the memoised top-level lists, a fresh process gets from the file (benchmarks/gen_tables.py writes one). */
+int bp_generators_save(bp_ctx* ctx, const char* path);
+int bp_generators_load(bp_ctx* ctx, const char* path);
 int bp_log_base2(const uint8_t* upper_bound, size_t len);
 int bp_transcript(int style, int which, const uint8_t* pts, const uint8_t* scs, const uint8_t* raw, size_t raw_len,
                   uint8_t* out);

@@ -135,6 +135,44 @@ def test_derive_generators_matches_oracle(engine):
     engine.set_generators(o.gs(128), o.hs(128), o.h())  # restore for the other tests
 
 
+def test_generator_table_file(engine, tmp_path):
+    """bp_generators_save / bp_generators_load: the file holds exactly the oracle's h, gs, hs (Utils.hs:14-25) with a
+    checksum; a loaded table verifies proofs like a derived one; corrupted and off-curve files are refused."""
+    import hashlib
+    import struct
+    n = 16
+    engine.derive_generators(n)
+    path = str(tmp_path / "gens.bin")
+    engine.save_generators(path)
+    raw = open(path, "rb").read()
+    body = raw[:-32]
+    assert body[:8] == b"BPGENS01" and struct.unpack("<4I", body[8:24]) == (n, 0, 0, 0)
+    assert body[24:] == _lib.enc_points(o.gs(n)) + _lib.enc_points(o.hs(n)) + _lib.enc_point(o.h())
+    assert raw[-32:] == hashlib.sha256(body).digest()
+    engine.set_generators(o.gs(128), o.hs(128), o.h())
+    engine.load_generators(path)
+    rng = random.Random(5)
+    vs = [(rng.randrange(0, 2**8), rng.randrange(1, R)) for _ in range(2)]
+    pr = o.mrp_generate_proof(2**8, vs, *o.draw_blinders(rng, 16))
+    vc = [o.commit(v, b) for v, b in vs]
+    sc, pts, _ = pack_batch([pr, dict(pr, mu=(pr["mu"] + 1) % R)], [vc, vc], 2)
+    assert engine.verify_batch(8, 2, 2, sc, pts) == [True, False]
+    # a flipped byte fails the checksum; an off-curve entry with a matching checksum fails the curve check
+    bad = bytearray(raw)
+    bad[200] ^= 1
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(_lib.BpError):
+        engine.load_generators(path)
+    off = bytearray(body)
+    off[24 + 32] ^= 1  # y of gs_1
+    open(path, "wb").write(bytes(off) + hashlib.sha256(bytes(off)).digest())
+    with pytest.raises(_lib.BpError):
+        engine.load_generators(path)
+    with pytest.raises(_lib.BpError):
+        engine.load_generators(str(tmp_path / "missing.bin"))
+    engine.set_generators(o.gs(128), o.hs(128), o.h())  # restore for the other tests
+
+
 def test_host_layer_verify_batch(eng_gens):
     """bp_rangeproof_verify_batch = map verifyProof, transcript hashed by the C++ host layer;
     chunked ping-pong pipeline must give the same verdicts as one chunk."""
