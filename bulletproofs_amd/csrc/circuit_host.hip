@@ -296,20 +296,28 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   // u = gen * shamirU tBlinding mu t   (:74-75)
   uint8_t ub[32], u[64];
   challenge_u(style, proof_scalars, ub);
-  if ((rc = point_mul_gen(ctx, w, g, ub, u)) != BP_OK) return rc;
-  if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
-  // commitmentLR (:77-85).  Expanding aiCommit, aoCommit, sCommit and mu, the same group element is
-  // <ls, gs> + <rs, hs'> + t*u for the prover's own ls, rs (an identity in the exponents, no
-  // circuit constraint needed), which is one MSM over the IPP base.
-  uint8_t P[64];
-  {
-    uint8_t* d_u = w.small;
-    BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = msm3(ctx, w, w.G, ls, 0, w.H, rs, 0, n2, d_u, t, P)) != BP_OK) return rc;
-  }
   std::vector<uint8_t> Lv, Rv;
-  rc = ipp_prove_core(ctx, w, n2, u, P, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
-  if (rc != BP_OK) return rc;
+  if (prover_uses_fixed_base()) {
+    // commitmentLR (:77-85) is, for the prover's own ls, rs, the commitment <ls, gs> + <rs, hs'> + t*u (expand
+    // aiCommit, aoCommit, sCommit and mu: an identity in the exponents, no circuit constraint needed), t = ls . rs:
+    // offset O; hs' = hs_i * y^-i (:76) enters as scalar factors
+    uint8_t D[64];
+    memset(D, 0, 64);
+    rc = ipp_prove_fixed(ctx, w, n2, d.yinv, ub, D, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
+    if (rc != BP_OK) return rc;
+  } else {
+    if ((rc = point_mul_gen(ctx, w, g, ub, u)) != BP_OK) return rc;
+    if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
+    // the same group element as one MSM over the materialised IPP base
+    uint8_t P[64];
+    {
+      uint8_t* d_u = w.small;
+      BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = msm3(ctx, w, w.G, ls, 0, w.H, rs, 0, n2, d_u, t, P)) != BP_OK) return rc;
+    }
+    rc = ipp_prove_core(ctx, w, n2, u, P, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
+    if (rc != BP_OK) return rc;
+  }
   if (k) {
     memcpy(proof_points + 640, Lv.data(), (size_t)k * 64);
     memcpy(proof_points + 640 + (size_t)k * 64, Rv.data(), (size_t)k * 64);

@@ -52,4 +52,20 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
                    std::vector<host::Fr4>& ls, std::vector<host::Fr4>& rs, host::ShowStyle style,
                    std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs, uint8_t l_out[32], uint8_t r_out[32]);
 
+// The same recursion when the base is the context's own generators: G = gs[0..n), H_i = hscale[i] * hs_i (the callers'
+// hs'), bH = gen * ub.  Nothing is folded on the device: with c_i the product of the challenges that the folds would
+// have put on generator i, every lCommit / rCommit / commitmentLR' is a multi-exponentiation over the ORIGINAL
+// generators with scalars l_j c_i (fbmsm.hip, fixed-base tables, no doublings); commitmentLR' = D + <l', G'> + <r', H'>
+// + <l', r'> bH with D = commitmentLR - (that sum for the initial l, r), which the folds leave unchanged
+// (commitmentLR' - commitment' = commitmentLR - commitment is the identity behind Prover.hs:87-92).
+// D: the caller's offset (O when commitmentLR is the commitment of ls, rs).  Same bytes as ipp_prove_core.
+int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<host::Fr4>& hscale, const uint8_t ub[32],
+                    const uint8_t D[64], std::vector<host::Fr4>& ls, std::vector<host::Fr4>& rs, host::ShowStyle style,
+                    std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs, uint8_t l_out[32], uint8_t r_out[32]);
+// BP_PROVER_FOLD=1 keeps the provers on ipp_prove_core (device-side generator folds)
+bool prover_uses_fixed_base();
+// fbmsm.hip
+int fb_msm_launch(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms, const uint8_t* d_scalars, const uint32_t* d_term_base,
+                  xyzz* d_partial, const uint8_t* d_offset, uint8_t* d_out);
+
 }  // namespace bp

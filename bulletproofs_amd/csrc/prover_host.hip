@@ -9,6 +9,7 @@
 // Randomness: the reference draws sL, sR, aBlinding, sBlinding, t1Blinding,
 // t2Blinding from MonadRandom in that order; here they are explicit arguments.
 #include "prover.h"
+#include "fixedbase.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -237,6 +238,149 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
     rs.resize(h);
     BP_TRY(hipStreamSynchronize(st));
     n = h;
+  }
+  fr_to_bytes(ls[0], l_out);
+  fr_to_bytes(rs[0], r_out);
+  return BP_OK;
+}
+
+bool prover_uses_fixed_base() {
+  static const bool fold = getenv("BP_PROVER_FOLD") && atoi(getenv("BP_PROVER_FOLD")) != 0;
+  return !fold;
+}
+
+int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<Fr4>& hscale, const uint8_t ub[32],
+                    const uint8_t D[64], std::vector<Fr4>& ls, std::vector<Fr4>& rs, ShowStyle style,
+                    std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs, uint8_t l_out[32], uint8_t r_out[32]) {
+  hipStream_t st = ctx->stream;
+  if (n == 0) {  // ([], []) -> InnerProductProof [] [] 0 0   (Prover.hs:42)
+    memset(l_out, 0, 32);
+    memset(r_out, 0, 32);
+    return BP_OK;
+  }
+  const uint32_t ng = ctx->n_gens;
+  if (n > ng || (n & (n - 1)) != 0) {
+    ctx->err = "ipp_prove_fixed: n must be a power of two within the context's generators";
+    return BP_ERR_ARG;
+  }
+  if (n == 1) {  // ([l], [r]): no round, commitmentLR is never hashed (Prover.hs:43)
+    fr_to_bytes(ls[0], l_out);
+    fr_to_bytes(rs[0], r_out);
+    return BP_OK;
+  }
+  const uint32_t nterms = 2 * n + 1, nblk = (nterms + 255) / 256;
+  // device scratch out of the prover workspace: scalars in w.sc, base indices + partial sums in w.pts
+  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 ||
+      (((size_t)nterms * 4 + 255) & ~(size_t)255) + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+    ctx->err = "ipp_prove_fixed: prover workspace too small";
+    return BP_ERR_STATE;
+  }
+  uint8_t* d_sc = w.sc;
+  uint32_t* d_tb = (uint32_t*)w.pts;
+  xyzz* d_part = (xyzz*)(w.pts + (((size_t)nterms * 4 + 255) & ~(size_t)255));
+  uint8_t* d_off = w.small;
+  uint8_t* d_out = w.small + 64;
+  {
+    std::vector<uint32_t> tb(nterms);
+    for (uint32_t i = 0; i < n; i++) {
+      tb[i] = fb_base_g(i);
+      tb[n + i] = fb_base_h(ng, i);
+    }
+    tb[2 * n] = fb_base_G(ng);
+    BP_TRY(hipMemcpyAsync(d_tb, tb.data(), (size_t)nterms * 4, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(d_off, D, 64, hipMemcpyHostToDevice, st));
+    BP_TRY(hipStreamSynchronize(st));  // tb lives on this frame
+  }
+  // fold coefficients of the original generators, in PLAIN form: a Montgomery product of a Montgomery-form
+  // and a plain operand is the plain product, so every scalar below comes out canonical with one multiplication
+  auto plain = [](const Fr4& a) {
+    Fr4 p;
+    fr_to_bytes(a, (uint8_t*)p.v);
+    return p;
+  };
+  std::vector<Fr4> cG(n), cH(n);
+  for (uint32_t i = 0; i < n; i++) {
+    cG[i] = Fr4{{1, 0, 0, 0}};
+    cH[i] = plain(hscale[i]);
+  }
+  const Fr4 ubm = fr_from_bytes(ub);
+  std::vector<uint8_t> hsc((size_t)3 * nterms * 32);
+  uint8_t out[3][64];
+  // commitment of (ls, rs) under the folded base, and the next lCommit / rCommit, as three sums over 2n + 1 generators
+  auto launch = [&](uint32_t nk) -> int {
+    const uint32_t h = nk / 2;
+    memset(hsc.data(), 0, hsc.size());
+    Fr4 dot = fr_zero(), cL = fr_zero(), cR = fr_zero();
+    for (uint32_t j = 0; j < nk; j++) dot = fr_add(dot, fr_mul(ls[j], rs[j]));
+    for (uint32_t j = 0; j < h; j++) {
+      cL = fr_add(cL, fr_mul(ls[j], rs[h + j]));  // dot lsLeft rsRight  (Prover.hs:60)
+      cR = fr_add(cR, fr_mul(ls[h + j], rs[j]));  // dot lsRight rsLeft  (:61)
+    }
+    uint8_t* C = hsc.data();
+    uint8_t* L = C + (size_t)nterms * 32;
+    uint8_t* R = L + (size_t)nterms * 32;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t j = i & (nk - 1);
+      Fr4 v = fr_mul(ls[j], cG[i]);
+      memcpy(C + (size_t)i * 32, v.v, 32);
+      v = fr_mul(rs[j], cH[i]);
+      memcpy(C + (size_t)(n + i) * 32, v.v, 32);
+      if (j >= h) {
+        // lCommit = sumExps lsLeft gsRight <> sumExps rsRight hsLeft <> bH * cL   (:63-67)
+        v = fr_mul(ls[j - h], cG[i]);
+        memcpy(L + (size_t)i * 32, v.v, 32);
+        // rCommit = sumExps lsRight gsLeft <> sumExps rsLeft hsRight <> bH * cR   (:69-73)
+        v = fr_mul(rs[j - h], cH[i]);
+        memcpy(R + (size_t)(n + i) * 32, v.v, 32);
+      } else {
+        v = fr_mul(rs[j + h], cH[i]);
+        memcpy(L + (size_t)(n + i) * 32, v.v, 32);
+        v = fr_mul(ls[j + h], cG[i]);
+        memcpy(R + (size_t)i * 32, v.v, 32);
+      }
+    }
+    fr_to_bytes(fr_mul(ubm, dot), C + (size_t)2 * n * 32);
+    fr_to_bytes(fr_mul(ubm, cL), L + (size_t)2 * n * 32);
+    fr_to_bytes(fr_mul(ubm, cR), R + (size_t)2 * n * 32);
+    BP_TRY(hipMemcpyAsync(d_sc, hsc.data(), hsc.size(), hipMemcpyHostToDevice, st));
+    int rc = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, d_out);
+    if (rc != BP_OK) return rc;
+    BP_TRY(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st));
+    BP_TRY(hipStreamSynchronize(st));
+    return BP_OK;
+  };
+  int rc;
+  uint32_t nk = n;
+  if ((rc = launch(nk)) != BP_OK) return rc;
+  while (nk > 1) {
+    const uint32_t h = nk / 2;
+    const uint8_t *P = out[0], *L = out[1], *R = out[2];
+    Ls.insert(Ls.end(), L, L + 64);
+    Rs.insert(Rs.end(), R, R + 64);
+    // x = shamirX' commitmentLR lCommit rCommit   (:75)
+    uint8_t buf[MSG_SCRATCH], xb[32];
+    Msg mm(buf, style);
+    mm.r();
+    mm.point(L);
+    mm.point(R);
+    mm.point(P);
+    mm.finish_fr(xb);
+    const Fr4 x = fr_from_bytes(xb), xi = fr_inv(x);
+    // gs'' = xInv*gsLeft + x*gsRight ; hs'' = x*hsLeft + xInv*hsRight   (:81-82), as coefficients
+    for (uint32_t i = 0; i < n; i++) {
+      const bool lo = (i & (nk - 1)) < h;
+      cG[i] = fr_mul(cG[i], lo ? xi : x);
+      cH[i] = fr_mul(cH[i], lo ? x : xi);
+    }
+    // ls' = x*lsLeft + xInv*lsRight ; rs' = xInv*rsLeft + x*rsRight   (:84-85)
+    for (uint32_t j = 0; j < h; j++) {
+      ls[j] = fr_add(fr_mul(x, ls[j]), fr_mul(xi, ls[h + j]));
+      rs[j] = fr_add(fr_mul(xi, rs[j]), fr_mul(x, rs[h + j]));
+    }
+    ls.resize(h);
+    rs.resize(h);
+    nk = h;
+    if (nk > 1 && (rc = launch(nk)) != BP_OK) return rc;  // commitmentLR' (:87-92) and the next lCommit, rCommit
   }
   fr_to_bytes(ls[0], l_out);
   fr_to_bytes(rs[0], r_out);
@@ -481,46 +625,70 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
   mu_.fr(proof_scalars + 32);
   mu_.fr(proof_scalars + 64);
   mu_.finish_fr(ub);
-  {
-    MsmSeg seg[1] = {{gen_h, 1, false}};
-    std::vector<Fr4> s1{fr_from_bytes(ub)};
-    MsmJob jobs[1] = {{seg, 1, &s1, u}};
-    if ((rc = msm_multi(ctx, w, jobs, 1)) != BP_OK) return rc;
-  }
-  // hs' = hs_i * recip(y^i)   (Prover.hs:107): one batched inversion on the host, one GLV kernel
-  {
-    std::vector<uint8_t> sc((size_t)nm * 32);
+  std::vector<uint8_t> Lv, Rv;
+  if (prover_uses_fixed_base()) {
+    // hs' = hs_i * recip(y^i) (Prover.hs:107) enters as scalar factors; commitmentLR (Prover.hs:108) is, for the
+    // prover's own ls, rs, t, the commitment <ls, gs> + <rs, hs'> + t*u (expand A, S, mu in
+    // RangeProof/Internal.hs:183-198) plus the digits of out-of-range values that only aCommit carries
+    std::vector<Fr4> hscale(nm);
     Fr4 yinv = fr_inv(y), cur = one;
     for (uint32_t i = 0; i < nm; i++) {
-      fr_to_bytes(cur, &sc[(size_t)i * 32]);
+      hscale[i] = cur;
       cur = fr_mul(cur, yinv);
     }
-    BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
-    if ((rc = ipp_scale_points(ctx, d_hs, w.sc, nm, w.tab, w.H)) != BP_OK) return rc;
-    BP_TRY(hipMemcpyAsync(w.G, d_gs, (size_t)nm * 64, hipMemcpyDeviceToDevice, st));
-    BP_TRY(hipStreamSynchronize(st));
-  }
-  // commitmentLR = computeLRCommitment ...   (Prover.hs:108).  For the prover's own ls, rs, t this is the
-  // same group element as <ls, gs> + <rs, hs'> + t*u (expand A, S, mu in RangeProof/Internal.hs:183-198),
-  // which is one MSM.
-  uint8_t P[64];
-  {
-    uint8_t* d_u = w.small;
-    BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, st));
-    if ((rc = msm3(ctx, w, w.G, ls, 0, w.H, rs, 0, nm, d_u, t, P)) != BP_OK) return rc;
-    if (n_digits > nm) {  // digits of out-of-range values that only aCommit carries
-      uint8_t extra[64], sum[64];
+    uint8_t D[64];
+    memset(D, 0, 64);
+    if (n_digits > nm) {
+      uint8_t* d_u = w.small;
+      BP_TRY(hipMemcpyAsync(d_u, gen_h, 64, hipMemcpyHostToDevice, st));  // any point: its scalar is zero
       if ((rc = msm3(ctx, w, d_gs + (size_t)nm * 64, aL, nm, d_hs + (size_t)nm * 64, aR, nm, n_digits - nm, d_u, zero,
-                     extra)) != BP_OK)
+                     D)) != BP_OK)
         return rc;
-      if ((rc = bp_point_add(ctx, P, extra, 1, sum)) != BP_OK) return rc;
-      memcpy(P, sum, 64);
     }
+    // productProof = IPP.generateProof (gs, hs', u) commitmentLR (ls, rs)   (Prover.hs:109-112)
+    rc = ipp_prove_fixed(ctx, w, nm, hscale, ub, D, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
+    if (rc != BP_OK) return rc;
+  } else {
+    {
+      MsmSeg seg[1] = {{gen_h, 1, false}};
+      std::vector<Fr4> s1{fr_from_bytes(ub)};
+      MsmJob jobs[1] = {{seg, 1, &s1, u}};
+      if ((rc = msm_multi(ctx, w, jobs, 1)) != BP_OK) return rc;
+    }
+    // hs' = hs_i * recip(y^i)   (Prover.hs:107): one batched inversion on the host, one GLV kernel
+    {
+      std::vector<uint8_t> sc((size_t)nm * 32);
+      Fr4 yinv = fr_inv(y), cur = one;
+      for (uint32_t i = 0; i < nm; i++) {
+        fr_to_bytes(cur, &sc[(size_t)i * 32]);
+        cur = fr_mul(cur, yinv);
+      }
+      BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+      if ((rc = ipp_scale_points(ctx, d_hs, w.sc, nm, w.tab, w.H)) != BP_OK) return rc;
+      BP_TRY(hipMemcpyAsync(w.G, d_gs, (size_t)nm * 64, hipMemcpyDeviceToDevice, st));
+      BP_TRY(hipStreamSynchronize(st));
+    }
+    // commitmentLR = computeLRCommitment ...   (Prover.hs:108).  For the prover's own ls, rs, t this is the
+    // same group element as <ls, gs> + <rs, hs'> + t*u (expand A, S, mu in RangeProof/Internal.hs:183-198),
+    // which is one MSM.
+    uint8_t P[64];
+    {
+      uint8_t* d_u = w.small;
+      BP_TRY(hipMemcpyAsync(d_u, u, 64, hipMemcpyHostToDevice, st));
+      if ((rc = msm3(ctx, w, w.G, ls, 0, w.H, rs, 0, nm, d_u, t, P)) != BP_OK) return rc;
+      if (n_digits > nm) {  // digits of out-of-range values that only aCommit carries
+        uint8_t extra[64], sum[64];
+        if ((rc = msm3(ctx, w, d_gs + (size_t)nm * 64, aL, nm, d_hs + (size_t)nm * 64, aR, nm, n_digits - nm, d_u, zero,
+                       extra)) != BP_OK)
+          return rc;
+        if ((rc = bp_point_add(ctx, P, extra, 1, sum)) != BP_OK) return rc;
+        memcpy(P, sum, 64);
+      }
+    }
+    // productProof = IPP.generateProof (gs, hs', u) commitmentLR (ls, rs)   (Prover.hs:109-112)
+    rc = ipp_prove_core(ctx, w, nm, u, P, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
+    if (rc != BP_OK) return rc;
   }
-  // productProof = IPP.generateProof (gs, hs', u) commitmentLR (ls, rs)   (Prover.hs:109-112)
-  std::vector<uint8_t> Lv, Rv;
-  rc = ipp_prove_core(ctx, w, nm, u, P, ls, rs, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128);
-  if (rc != BP_OK) return rc;
   if (k) {
     memcpy(proof_points + 256, Lv.data(), (size_t)k * 64);
     memcpy(proof_points + 256 + (size_t)k * 64, Rv.data(), (size_t)k * 64);
