@@ -10,6 +10,7 @@
 // Randomness: aiBlinding, aoBlinding, sBlinding, sL, sR and the five
 // tBlindings are explicit arguments in the reference's draw order.
 #include "prover.h"
+#include "fixedbase.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -206,7 +207,25 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   uint8_t* S = proof_points + 128;
   uint8_t* T = proof_points + 192;  // 7 points
   // commitBitVector (Internal.hs:102-107): aiCommit, aoCommit (vR = []), sCommit   (Prover.hs:29-33)
-  {  // the three commitments in one launch
+  if (prover_uses_fixed_base() && n2 > 0) {  // the three commitments through the fixed-base tables, one launch
+    const uint32_t ng = ctx->n_gens;
+    std::vector<uint32_t> tb(2 * (size_t)n2 + 1);
+    for (uint32_t i = 0; i < n2; i++) {
+      tb[i] = fb_base_g(i);
+      tb[n2 + i] = fb_base_h(ng, i);
+    }
+    tb[2 * (size_t)n2] = fb_base_H(ng);
+    std::vector<Fr4> scI(aL), scO(aO), scS(sL);
+    scI.insert(scI.end(), aR.begin(), aR.end());
+    scI.push_back(aiB);
+    scO.resize(2 * (size_t)n2, zero);  // vR = []
+    scO.push_back(aoB);
+    scS.insert(scS.end(), sR.begin(), sR.end());
+    scS.push_back(sB);
+    const std::vector<Fr4>* scs[3] = {&scI, &scO, &scS};
+    uint8_t* outs[3] = {AI, AO, S};
+    if ((rc = fb_msm_host(ctx, w, tb, 3, scs, outs)) != BP_OK) return rc;
+  } else {  // the three commitments in one launch
     MsmSeg segI[3] = {{g.d_gs, n2, true}, {g.d_hs, n2, true}, {g.d_h, 1, true}};
     MsmSeg segO[2] = {{g.d_gs, n2, true}, {g.d_h, 1, true}};
     std::vector<Fr4> scI(aL), scO(aO), scS(sL);
@@ -245,7 +264,19 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   // tBlindings = insertAt 2 0 (0 : five randoms); tCommits = zipWith commit tPoly tBlindings   (Prover.hs:57-58)
   Fr4 tau[7] = {zero, fr_from_bytes(tau5), zero, fr_from_bytes(tau5 + 32), fr_from_bytes(tau5 + 64),
                 fr_from_bytes(tau5 + 96), fr_from_bytes(tau5 + 128)};
-  {  // seven lanes of one GLV kernel: T_i = t_i * gen + tau_i * h
+  if (prover_uses_fixed_base()) {  // seven two-term sums over gen, h through the fixed-base tables
+    const uint32_t ng = ctx->n_gens;
+    std::vector<uint32_t> tb{fb_base_G(ng), fb_base_H(ng)};
+    std::vector<Fr4> sc7[7];
+    const std::vector<Fr4>* scs[7];
+    uint8_t* outs[7];
+    for (int i = 0; i < 7; i++) {
+      sc7[i] = {tc[i], tau[i]};
+      scs[i] = &sc7[i];
+      outs[i] = T + 64 * i;
+    }
+    if ((rc = fb_msm_host(ctx, w, tb, 7, scs, outs)) != BP_OK) return rc;
+  } else {  // seven lanes of one GLV kernel: T_i = t_i * gen + tau_i * h
     uint8_t e[14 * 32];
     for (int i = 0; i < 7; i++) {
       fr_to_bytes(tc[i], e + 32 * i);

@@ -62,6 +62,10 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
 int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<host::Fr4>& hscale, const uint8_t ub[32],
                     const uint8_t D[64], std::vector<host::Fr4>& ls, std::vector<host::Fr4>& rs, host::ShowStyle style,
                     std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs, uint8_t l_out[32], uint8_t r_out[32]);
+// Up to 15 sums over the context's generators in one launch pair through the fixed-base tables:
+// outs[j] = sum_t (*scalars[j])[t] * base(term_base[t]) (fixedbase.h numbering; scalars in Montgomery form).  Synchronous.
+int fb_msm_host(bp_ctx* ctx, ProverWs& w, const std::vector<uint32_t>& term_base, uint32_t nmsm,
+                const std::vector<host::Fr4>* const* scalars, uint8_t* const* outs);
 // BP_PROVER_FOLD=1 keeps the provers on ipp_prove_core (device-side generator folds)
 bool prover_uses_fixed_base();
 // fbmsm.hip

@@ -244,6 +244,35 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
   return BP_OK;
 }
 
+int fb_msm_host(bp_ctx* ctx, ProverWs& w, const std::vector<uint32_t>& term_base, uint32_t nmsm,
+                const std::vector<Fr4>* const* scalars, uint8_t* const* outs) {
+  hipStream_t st = ctx->stream;
+  const uint32_t nterms = (uint32_t)term_base.size(), nblk = (nterms + 255) / 256;
+  BP_REQUIRE(nmsm >= 1 && nmsm <= 15 && nterms >= 1, "fb_msm_host: 1..15 sums over at least one term");
+  const size_t tb_bytes = ((size_t)nterms * 4 + 255) & ~(size_t)255;
+  if ((size_t)nmsm * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + (size_t)nmsm * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+    ctx->err = "fb_msm_host: prover workspace too small";
+    return BP_ERR_STATE;
+  }
+  std::vector<uint8_t> hsc((size_t)nmsm * nterms * 32);
+  for (uint32_t j = 0; j < nmsm; j++) {
+    BP_REQUIRE(scalars[j]->size() == nterms, "fb_msm_host: scalar count does not match the terms");
+    for (uint32_t t = 0; t < nterms; t++) fr_to_bytes((*scalars[j])[t], &hsc[((size_t)j * nterms + t) * 32]);
+  }
+  uint32_t* d_tb = (uint32_t*)w.pts;
+  xyzz* d_part = (xyzz*)(w.pts + tb_bytes);
+  uint8_t* d_out = w.small + 64;
+  BP_TRY(hipMemcpyAsync(d_tb, term_base.data(), (size_t)nterms * 4, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(w.sc, hsc.data(), hsc.size(), hipMemcpyHostToDevice, st));
+  int rc = fb_msm_launch(ctx, nmsm, nterms, w.sc, d_tb, d_part, nullptr, d_out);
+  if (rc != BP_OK) return rc;
+  uint8_t out[15 * 64];
+  BP_TRY(hipMemcpyAsync(out, d_out, (size_t)nmsm * 64, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  for (uint32_t j = 0; j < nmsm; j++) memcpy(outs[j], out + (size_t)j * 64, 64);
+  return BP_OK;
+}
+
 bool prover_uses_fixed_base() {
   static const bool fold = getenv("BP_PROVER_FOLD") && atoi(getenv("BP_PROVER_FOLD")) != 0;
   return !fold;
@@ -532,7 +561,22 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
   uint8_t* T1 = proof_points + 128;
   uint8_t* T2 = proof_points + 192;
   // commitBitVectors: A = aBlinding*h + <aL, gs> + <aR, hs>, S likewise   (RangeProof/Internal.hs:136-147)
-  {  // both commitments in one launch
+  if (prover_uses_fixed_base() && n_digits == nm) {  // both commitments through the fixed-base tables, one launch
+    std::vector<uint32_t> tb(2 * (size_t)nm + 1);
+    for (uint32_t i = 0; i < nm; i++) {
+      tb[i] = fb_base_g(i);
+      tb[nm + i] = fb_base_h(ng, i);
+    }
+    tb[2 * (size_t)nm] = fb_base_H(ng);
+    std::vector<Fr4> scA(aL), scS(sLv);
+    scA.insert(scA.end(), aR.begin(), aR.end());
+    scA.push_back(fr_from_bytes(alpha));
+    scS.insert(scS.end(), sRv.begin(), sRv.end());
+    scS.push_back(fr_from_bytes(rho));
+    const std::vector<Fr4>* scs[2] = {&scA, &scS};
+    uint8_t* outs[2] = {A, S};
+    if ((rc = fb_msm_host(ctx, w, tb, 2, scs, outs)) != BP_OK) return rc;
+  } else {  // both commitments in one launch
     MsmSeg segA[3] = {{d_gs, n_digits, true}, {d_hs, n_digits, true}, {d_h, 1, true}};
     MsmSeg segS[3] = {{d_gs, nm, true}, {d_hs, nm, true}, {d_h, 1, true}};
     std::vector<Fr4> scA(aL), scS(sLv);
@@ -583,7 +627,13 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
     t1 = fr_add(t1, fr_add(fr_mul(sLv[i], r0[i]), fr_mul(l0[i], r1[i])));
   }
   // t1Commit = commit t1 t1Blinding, t2Commit likewise   (Prover.hs:84-85; Utils.hs:84-85)
-  {
+  if (prover_uses_fixed_base()) {
+    std::vector<uint32_t> tb{fb_base_G(ng), fb_base_H(ng)};
+    std::vector<Fr4> s1{t1, fr_from_bytes(tau1)}, s2{t2, fr_from_bytes(tau2)};
+    const std::vector<Fr4>* scs[2] = {&s1, &s2};
+    uint8_t* outs[2] = {T1, T2};
+    if ((rc = fb_msm_host(ctx, w, tb, 2, scs, outs)) != BP_OK) return rc;
+  } else {
     MsmSeg seg[1] = {{gen_h, 2, false}};
     std::vector<Fr4> s1{t1, fr_from_bytes(tau1)}, s2{t2, fr_from_bytes(tau2)};
     MsmJob jobs[2] = {{seg, 1, &s1, T1}, {seg, 1, &s2, T2}};
