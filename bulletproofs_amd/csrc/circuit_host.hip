@@ -397,7 +397,22 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   fr_to_bytes(mu, canon3 + 32);
   fr_to_bytes(t, canon3 + 64);
   challenge_u(style, canon3, ub);
-  if ((rc = point_mul_gen(ctx, w, g, ub, u)) != BP_OK) return rc;
+  // with the fixed-base tables u = gen * ub and hs' = hs_i * y^-i never exist as points: both enter as scalar factors
+  const bool fixed = prover_uses_fixed_base() && n2 > 0;
+  const Fr4 ubm = fr_from_bytes(ub);
+  std::vector<uint32_t> tb_gh;  // gs_0.., hs_0.., h, gen
+  if (fixed) {
+    const uint32_t ng = ctx->n_gens;
+    tb_gh.resize(2 * (size_t)n2 + 2);
+    for (uint32_t i = 0; i < n2; i++) {
+      tb_gh[i] = fb_base_g(i);
+      tb_gh[n2 + i] = fb_base_h(ng, i);
+    }
+    tb_gh[2 * (size_t)n2] = fb_base_H(ng);
+    tb_gh[2 * (size_t)n2 + 1] = fb_base_G(ng);
+  } else if ((rc = point_mul_gen(ctx, w, g, ub, u)) != BP_OK) {
+    return rc;
+  }
 
   // verifyTPoly (:43-54): commit t tBlinding == gen*gExp + sumExps xs tCommits + sumExps vExp vCommits,
   // evaluated as one multiexp of the difference, which is O exactly when both sides are equal.
@@ -431,9 +446,32 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   }
 
   // verifyLRCommitment (:56-71)
-  if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
   uint8_t acc[64];
-  {
+  if (fixed) {
+    // commitmentLR = x*AI + x^2*AO + x^3*S + sumExps gExp gs + sumExps hExp hs' - mu*h + t*u: the generator part
+    // through the tables, the three proof points as one short multiexp, one addition
+    std::vector<Fr4> sc(2 * (size_t)n2 + 2);
+    for (uint32_t i = 0; i < n2; i++) {
+      sc[i] = fr_mul(x, fr_mul(d.yinv[i], d.zwR[i]));
+      sc[n2 + i] = fr_mul(fr_sub(fr_add(fr_mul(x, d.zwL[i]), d.zwO[i]), d.ys[i]), d.yinv[i]);
+    }
+    sc[2 * (size_t)n2] = fr_neg(mu);
+    sc[2 * (size_t)n2 + 1] = fr_mul(t, ubm);
+    uint8_t fpart[64], vpart[64];
+    const std::vector<Fr4>* scs[1] = {&sc};
+    uint8_t* outs[1] = {fpart};
+    if ((rc = fb_msm_host(ctx, w, tb_gh, 1, scs, outs)) != BP_OK) return rc;
+    uint8_t three[3 * 64];
+    memcpy(three, AI, 64);
+    memcpy(three + 64, AO, 64);
+    memcpy(three + 128, S, 64);
+    std::vector<Fr4> sv{x, x2, x3};
+    MsmSeg segs[1] = {{three, 3, false}};
+    MsmJob vjobs[1] = {{segs, 1, &sv, vpart}};
+    if ((rc = msm_multi(ctx, w, vjobs, 1)) != BP_OK) return rc;
+    if ((rc = bp_point_add(ctx, fpart, vpart, 1, acc)) != BP_OK) return rc;
+  } else {
+    if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
     // commitmentLR = x*AI + x^2*AO + x^3*S + sumExps gExp gs + sumExps hExp hs' - mu*h + t*u
     std::vector<Fr4> sc(2 * (size_t)n2);
     for (uint32_t i = 0; i < n2; i++) {
@@ -463,6 +501,12 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
     uint8_t* d_R = w.small + 192;
     uint8_t* d_new = w.small + 256;
     BP_TRY(hipMemcpyAsync(d_acc, acc, 64, hipMemcpyHostToDevice, st));
+    // the proof's L_j, R_j are known up front: their shifted forms let eight lanes share each round's chain
+    const bool split = prover_uses_fixed_base() && k > 0 && 2 * k <= 32;
+    if (split) {
+      BP_TRY(hipMemcpyAsync(w.split_pts, Lp, (size_t)2 * k * 64, hipMemcpyHostToDevice, st));
+      if ((rc = ipp_shift_points(ctx, w.split_pts, 2 * k, w.split_sh)) != BP_OK) return rc;
+    }
     for (uint32_t j = 0; j < k; j++) {
       const uint8_t* Lj = Lp + (size_t)j * 64;
       const uint8_t* Rj = Rp + (size_t)j * 64;
@@ -476,9 +520,15 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
       chal[j] = fr_from_bytes(xjb);
       fr_to_bytes(fr_sqr(chal[j]), x2b);
       fr_to_bytes(fr_sqr(fr_inv(chal[j])), xi2b);
-      BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
-      BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
-      if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
+      if (split) {
+        if ((rc = ipp_lincomb2_add_split(ctx, w.split_sh + (size_t)j * IPP_SPLIT_S, w.split_sh + (size_t)(k + j) * IPP_SPLIT_S,
+                                         d_acc, x2b, xi2b, w.split_tab, d_new)) != BP_OK)
+          return rc;
+      } else {
+        BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
+        BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
+        if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
+      }
       BP_TRY(hipMemcpyAsync(acc, d_new, 64, hipMemcpyDeviceToHost, st));
       BP_TRY(hipMemcpyAsync(d_acc, d_new, 64, hipMemcpyDeviceToDevice, st));
       BP_TRY(hipStreamSynchronize(st));
@@ -496,15 +546,28 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
       s[i1] = fr_mul(s[i1 - (1u << j)], fr_sqr(chal[k - 1 - j]));
     }
     // cProof = l*<s, gs> + r*<reverse s, hs'> + (l*r)*u   (:27-36)
-    std::vector<Fr4> sc(2 * (size_t)n2 + 1);
-    for (uint32_t i = 0; i < n2; i++) {
-      sc[i] = fr_mul(l, s[i]);
-      sc[n2 + i] = fr_mul(r, s[n2 - 1 - i]);
-    }
-    sc[2 * (size_t)n2] = fr_mul(l, r);
-    MsmSeg segs[3] = {{w.G, n2, true}, {w.H, n2, true}, {u, 1, false}};
     uint8_t cproof[64];
-    if ((rc = msm_gather(ctx, w, segs, 3, sc, cproof)) != BP_OK) return rc;
+    if (fixed) {
+      std::vector<Fr4> sc(2 * (size_t)n2 + 2);
+      for (uint32_t i = 0; i < n2; i++) {
+        sc[i] = fr_mul(l, s[i]);
+        sc[n2 + i] = fr_mul(fr_mul(r, s[n2 - 1 - i]), d.yinv[i]);
+      }
+      sc[2 * (size_t)n2] = zero;  // h
+      sc[2 * (size_t)n2 + 1] = fr_mul(fr_mul(l, r), ubm);
+      const std::vector<Fr4>* scs[1] = {&sc};
+      uint8_t* outs[1] = {cproof};
+      if ((rc = fb_msm_host(ctx, w, tb_gh, 1, scs, outs)) != BP_OK) return rc;
+    } else {
+      std::vector<Fr4> sc(2 * (size_t)n2 + 1);
+      for (uint32_t i = 0; i < n2; i++) {
+        sc[i] = fr_mul(l, s[i]);
+        sc[n2 + i] = fr_mul(r, s[n2 - 1 - i]);
+      }
+      sc[2 * (size_t)n2] = fr_mul(l, r);
+      MsmSeg segs[3] = {{w.G, n2, true}, {w.H, n2, true}, {u, 1, false}};
+      if ((rc = msm_gather(ctx, w, segs, 3, sc, cproof)) != BP_OK) return rc;
+    }
     lr_ok = memcmp(cproof, acc, 64) == 0;
   }
   *verdict = (lr_ok && t_ok) ? 1 : 0;

@@ -128,6 +128,11 @@ int msm_direct_multi(bp_ctx* ctx, const uint8_t* d_scalars, const uint8_t* d_poi
 size_t msm_direct_limit();
 int ipp_fold_points(bp_ctx* ctx, const uint8_t* d_lo, const uint8_t* d_hi, uint32_t n, const uint8_t s_lo[32],
                     const uint8_t s_hi[32], xyzz* d_tab, uint8_t* d_out);
+// the same through 8 lanes: d_sh = 2^(17 s) * p for s < 8 (ipp_shift_points, once per point), d_tab: 15 x 64 xyzz
+constexpr int IPP_SPLIT_S = 8;
+int ipp_shift_points(bp_ctx* ctx, const uint8_t* d_pts, uint32_t n, xyzz* d_sh);
+int ipp_lincomb2_add_split(bp_ctx* ctx, const xyzz* d_sh0, const xyzz* d_sh1, const uint8_t* d_p2, const uint8_t k0[32],
+                           const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out);
 int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, const uint8_t* d_p2, const uint8_t k0[32],
                      const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out);
 int ipp_scale_points(bp_ctx* ctx, const uint8_t* d_pts, const uint8_t* d_scalars, uint32_t n, xyzz* d_tab,

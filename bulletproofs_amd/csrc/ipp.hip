@@ -59,6 +59,84 @@ __global__ void __launch_bounds__(64) k_lincomb2_add(const uint8_t* __restrict__
   st_affine(out, xyzz_to_affine(acc));
 }
 
+// ---- the same group element with the 129 steps spread over SPLIT_S lanes ---------------------------------
+// A single proof's verifier walks one k0*p0 + k1*p1 + p2 per round (mkChallenges,
+// InnerProductProof/Verifier.hs:47-50), a 129-step double-and-add chain that one lane runs in ~1.5 ms while the
+// rest of the GPU idles.  p0, p1 (the proof's L_j, R_j) are known before any challenge: k_shift_points computes
+// 2^(SPLIT_W s) * p for s < SPLIT_S once for all rounds, and lane s of k_lincomb2_add_split then handles bits
+// [SPLIT_W s, SPLIT_W s + SPLIT_W) of the four GLV halves on the points shifted by 2^(SPLIT_W s): 17 steps per
+// lane, a shuffle sum over the lanes, one normalisation.  Exact: the lanes' partial sums add up to the same element.
+constexpr int SPLIT_S = 8, SPLIT_W = 17;  // 8 x 17 = 136 >= GLV_BITS
+
+__global__ void __launch_bounds__(64) k_shift_points(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][SPLIT_S]*/) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  xyzz a = xyzz_from_affine(ld_affine(pts + (size_t)i * 64));
+  st_xyzz(&sh[(size_t)i * SPLIT_S], a);
+#pragma unroll 1
+  for (int s = 1; s < SPLIT_S; s++) {
+#pragma unroll 1
+    for (int b = 0; b < SPLIT_W; b++) a = xyzz_dbl(a);
+    st_xyzz(&sh[(size_t)i * SPLIT_S + s], a);
+  }
+}
+
+__device__ __forceinline__ uint32_t mag_bit(const uint32_t (&m)[5], int i) {
+  const int w = i >> 5;
+  uint32_t v = m[0];
+  v = w == 1 ? m[1] : v;
+  v = w == 2 ? m[2] : v;
+  v = w == 3 ? m[3] : v;
+  v = w >= 4 ? m[4] : v;
+  return (v >> (i & 31)) & 1u;
+}
+__device__ __forceinline__ xyzz xyzz_phi(const xyzz& p) {  // (beta X, Y, ZZ, ZZZ); the identity stays the identity
+  const uint32_t BETA[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
+  xyzz r = p;
+  r.X = fq_mul(p.X, glv_const(BETA));
+  return r;
+}
+
+// out = k0*p0 + k1*p1 + p2 from the shifted forms sh0, sh1 ([SPLIT_S] each) of p0, p1; one wave, tab: 15 x 64 xyzz
+__global__ void __launch_bounds__(64) k_lincomb2_add_split(const xyzz* __restrict__ sh0, const xyzz* __restrict__ sh1,
+                                                          const uint8_t* __restrict__ p2, u256 k0, u256 k1,
+                                                          xyzz* __restrict__ tab, uint8_t* __restrict__ out) {
+  const int s = threadIdx.x;
+  xyzz acc = xyzz_inf();
+  if (s < SPLIT_S) {
+    auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * 64 + s], v); };
+    auto load = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * 64 + s]); };
+    GlvHalf a1, a2, b1, b2;
+    glv_split(k0, a1, a2);
+    glv_split(k1, b1, b2);
+    xyzz P0 = ld_xyzz(&sh0[s]), P1 = ld_xyzz(&sh1[s]);
+    xyzz Q0 = xyzz_phi(P0), Q1 = xyzz_phi(P1);
+    store(1, a1.neg ? xyzz_neg(P0) : P0);
+    store(2, a2.neg ? xyzz_neg(Q0) : Q0);
+    store(4, b1.neg ? xyzz_neg(P1) : P1);
+    store(8, b2.neg ? xyzz_neg(Q1) : Q1);
+#pragma unroll 1
+    for (int e = 3; e < 16; e++) {
+      int top = 31 - __builtin_clz((unsigned)e);
+      int rest = e & ~(1 << top);
+      if (rest == 0) continue;
+      store(e, xyzz_add(load(rest), load(1 << top)));
+    }
+#pragma unroll 1
+    for (int b = SPLIT_W - 1; b >= 0; b--) {
+      const int pos = SPLIT_W * s + b;
+      uint32_t idx = mag_bit(a1.m, pos) | (mag_bit(a2.m, pos) << 1) | (mag_bit(b1.m, pos) << 2) | (mag_bit(b2.m, pos) << 3);
+      acc = xyzz_dbl(acc);
+      if (idx) acc = xyzz_add(acc, load((int)idx));
+    }
+  }
+  acc = wave_sum(acc);  // lanes >= SPLIT_S hold the identity
+  if (s == 0) {
+    acc = xyzz_madd(acc, ld_affine(p2));
+    st_affine(out, xyzz_to_affine(acc));
+  }
+}
+
 // out[i] = scalars[i] * pts[i], independent scalars (canonical, 32 B each): GLV, one lane per i
 __global__ void __launch_bounds__(256) k_scale_points(const uint8_t* __restrict__ pts, const uint8_t* __restrict__ scalars,
                                                      uint32_t n, xyzz* __restrict__ tab, uint8_t* __restrict__ out) {
@@ -140,6 +218,22 @@ int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, cons
   memcpy(a.v, k0, 32);
   memcpy(b.v, k1, 32);
   hipLaunchKernelGGL(k_lincomb2_add, dim3(1), dim3(64), 0, ctx->stream, d_p0, d_p1, d_p2, a, b, d_tab, d_out);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+int ipp_shift_points(bp_ctx* ctx, const uint8_t* d_pts, uint32_t n, xyzz* d_sh) {
+  hipLaunchKernelGGL(k_shift_points, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_pts, n, d_sh);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+int ipp_lincomb2_add_split(bp_ctx* ctx, const xyzz* d_sh0, const xyzz* d_sh1, const uint8_t* d_p2, const uint8_t k0[32],
+                           const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out) {
+  u256 a, b;
+  memcpy(a.v, k0, 32);
+  memcpy(b.v, k1, 32);
+  hipLaunchKernelGGL(k_lincomb2_add_split, dim3(1), dim3(64), 0, ctx->stream, d_sh0, d_sh1, d_p2, a, b, d_tab, d_out);
   BP_TRY(hipGetLastError());
   return BP_OK;
 }

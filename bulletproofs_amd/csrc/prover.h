@@ -17,6 +17,9 @@ struct ProverWs {
   uint8_t* sc;       // MSM scalars, same layout
   uint8_t* small;    // 16 single points: u, P, L, R, ...; slots 12..15 = MSM outputs
   xyzz* tab;         // 15 * (n + 2) joint-table scratch
+  xyzz* split_tab;   // 15 x 64 joint tables of the lane-split round kernel (ipp.hip)
+  xyzz* split_sh;    // shifted forms of up to 32 points (L_j, R_j of a proof), 8 each
+  uint8_t* split_pts;  // those points, affine
 };
 
 // carve the workspace for vectors of n points out of ctx->pws (grown on demand); `extra` more gathered terms

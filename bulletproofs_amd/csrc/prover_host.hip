@@ -28,6 +28,9 @@ int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra) {
     w.sc = c.take<uint8_t>(4 * w.seg_cap * 32);
     w.small = c.take<uint8_t>(16 * 64);
     w.tab = c.take<xyzz>((size_t)15 * (n + 2));
+    w.split_tab = c.take<xyzz>((size_t)15 * 64);
+    w.split_sh = c.take<xyzz>((size_t)32 * IPP_SPLIT_S);
+    w.split_pts = c.take<uint8_t>((size_t)32 * 64);
     return c.off;
   };
   size_t need = carve(nullptr);
