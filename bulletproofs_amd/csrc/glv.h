@@ -205,6 +205,54 @@ BP_HD xyzz glv_pair_multiexp_tab(const u256& k0, const u256& k1, LoadAff load) {
   return acc;
 }
 
+// ---- one k0*p0 + k1*p1 spread over SPLIT_S lanes --------------------------------------------------------
+// Lane s handles bits [SPLIT_W s, SPLIT_W s + SPLIT_W) of the four signed GLV halves on the points shifted by
+// 2^(SPLIT_W s) (P0s = 2^(SPLIT_W s) p0, P1s likewise, XYZZ): SPLIT_W doublings and additions instead of 129.
+// The lanes' results add up to k0*p0 + k1*p1.  store/load: this lane's 15 joint-table slots.
+constexpr int SPLIT_S = 8, SPLIT_W = 17;  // 8 x 17 = 136 >= GLV_BITS
+BP_HD uint32_t mag_bit(const uint32_t (&m)[5], int i) {
+  const int w = i >> 5;
+  uint32_t v = m[0];
+  v = w == 1 ? m[1] : v;
+  v = w == 2 ? m[2] : v;
+  v = w == 3 ? m[3] : v;
+  v = w >= 4 ? m[4] : v;
+  return (v >> (i & 31)) & 1u;
+}
+BP_HD xyzz xyzz_phi(const xyzz& p) {  // (beta X, Y, ZZ, ZZZ); the identity stays the identity
+  const uint32_t BETA[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
+  xyzz r = p;
+  r.X = fq_mul(p.X, glv_const(BETA));
+  return r;
+}
+template <class Store, class Load>
+BP_HD xyzz glv_split_lane(const u256& k0, const u256& k1, const xyzz& P0s, const xyzz& P1s, int s, Store store, Load load) {
+  GlvHalf a1, a2, b1, b2;
+  glv_split(k0, a1, a2);
+  glv_split(k1, b1, b2);
+  xyzz Q0 = xyzz_phi(P0s), Q1 = xyzz_phi(P1s);
+  store(1, a1.neg ? xyzz_neg(P0s) : P0s);
+  store(2, a2.neg ? xyzz_neg(Q0) : Q0);
+  store(4, b1.neg ? xyzz_neg(P1s) : P1s);
+  store(8, b2.neg ? xyzz_neg(Q1) : Q1);
+#pragma unroll 1
+  for (int e = 3; e < 16; e++) {
+    int top = 31 - __builtin_clz((unsigned)e);
+    int rest = e & ~(1 << top);
+    if (rest == 0) continue;
+    store(e, xyzz_add(load(rest), load(1 << top)));
+  }
+  xyzz acc = xyzz_inf();
+#pragma unroll 1
+  for (int b = SPLIT_W - 1; b >= 0; b--) {
+    const int pos = SPLIT_W * s + b;
+    uint32_t idx = mag_bit(a1.m, pos) | (mag_bit(a2.m, pos) << 1) | (mag_bit(b1.m, pos) << 2) | (mag_bit(b2.m, pos) << 3);
+    acc = xyzz_dbl(acc);
+    if (idx) acc = xyzz_add(acc, load((int)idx));
+  }
+  return acc;
+}
+
 // Host-testable construction of that table (the device builds it with one shared inversion, verify.hip):
 // tab[e], e in [1, 16); tab[0] unused.
 BP_HD void glv_pair_table_local(const affine& P0, const affine& P1, affine* tab) {

@@ -66,8 +66,6 @@ __global__ void __launch_bounds__(64) k_lincomb2_add(const uint8_t* __restrict__
 // 2^(SPLIT_W s) * p for s < SPLIT_S once for all rounds, and lane s of k_lincomb2_add_split then handles bits
 // [SPLIT_W s, SPLIT_W s + SPLIT_W) of the four GLV halves on the points shifted by 2^(SPLIT_W s): 17 steps per
 // lane, a shuffle sum over the lanes, one normalisation.  Exact: the lanes' partial sums add up to the same element.
-constexpr int SPLIT_S = 8, SPLIT_W = 17;  // 8 x 17 = 136 >= GLV_BITS
-
 __global__ void __launch_bounds__(64) k_shift_points(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][SPLIT_S]*/) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -81,22 +79,6 @@ __global__ void __launch_bounds__(64) k_shift_points(const uint8_t* __restrict__
   }
 }
 
-__device__ __forceinline__ uint32_t mag_bit(const uint32_t (&m)[5], int i) {
-  const int w = i >> 5;
-  uint32_t v = m[0];
-  v = w == 1 ? m[1] : v;
-  v = w == 2 ? m[2] : v;
-  v = w == 3 ? m[3] : v;
-  v = w >= 4 ? m[4] : v;
-  return (v >> (i & 31)) & 1u;
-}
-__device__ __forceinline__ xyzz xyzz_phi(const xyzz& p) {  // (beta X, Y, ZZ, ZZZ); the identity stays the identity
-  const uint32_t BETA[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
-  xyzz r = p;
-  r.X = fq_mul(p.X, glv_const(BETA));
-  return r;
-}
-
 // out = k0*p0 + k1*p1 + p2 from the shifted forms sh0, sh1 ([SPLIT_S] each) of p0, p1; one wave, tab: 15 x 64 xyzz
 __global__ void __launch_bounds__(64) k_lincomb2_add_split(const xyzz* __restrict__ sh0, const xyzz* __restrict__ sh1,
                                                           const uint8_t* __restrict__ p2, u256 k0, u256 k1,
@@ -106,29 +88,7 @@ __global__ void __launch_bounds__(64) k_lincomb2_add_split(const xyzz* __restric
   if (s < SPLIT_S) {
     auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * 64 + s], v); };
     auto load = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * 64 + s]); };
-    GlvHalf a1, a2, b1, b2;
-    glv_split(k0, a1, a2);
-    glv_split(k1, b1, b2);
-    xyzz P0 = ld_xyzz(&sh0[s]), P1 = ld_xyzz(&sh1[s]);
-    xyzz Q0 = xyzz_phi(P0), Q1 = xyzz_phi(P1);
-    store(1, a1.neg ? xyzz_neg(P0) : P0);
-    store(2, a2.neg ? xyzz_neg(Q0) : Q0);
-    store(4, b1.neg ? xyzz_neg(P1) : P1);
-    store(8, b2.neg ? xyzz_neg(Q1) : Q1);
-#pragma unroll 1
-    for (int e = 3; e < 16; e++) {
-      int top = 31 - __builtin_clz((unsigned)e);
-      int rest = e & ~(1 << top);
-      if (rest == 0) continue;
-      store(e, xyzz_add(load(rest), load(1 << top)));
-    }
-#pragma unroll 1
-    for (int b = SPLIT_W - 1; b >= 0; b--) {
-      const int pos = SPLIT_W * s + b;
-      uint32_t idx = mag_bit(a1.m, pos) | (mag_bit(a2.m, pos) << 1) | (mag_bit(b1.m, pos) << 2) | (mag_bit(b2.m, pos) << 3);
-      acc = xyzz_dbl(acc);
-      if (idx) acc = xyzz_add(acc, load((int)idx));
-    }
+    acc = glv_split_lane(k0, k1, ld_xyzz(&sh0[s]), ld_xyzz(&sh1[s]), s, store, load);
   }
   acc = wave_sum(acc);  // lanes >= SPLIT_S hold the identity
   if (s == 0) {

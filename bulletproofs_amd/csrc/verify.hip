@@ -420,6 +420,67 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   if (host_txt) block_store_point_text(lds, out, host_txt, d.B);
 }
 
+// ---- small batches: a round through eight lanes per proof (glv.h, glv_split_lane) -------------------------
+// With a handful of proofs the 129-step chain of k_round leaves the GPU idle and sets the latency of a
+// verification.  The proof's L_r, R_r are known before any challenge: k_vshift computes 2^(17 s) * P for s < 8
+// once (side stream, beside stage 1), and k_round_split gives every proof one wave whose lanes 0..7 each walk
+// 17 bits of the four GLV halves on the shifted points; a shuffle sum, the old commitment, one normalisation.
+constexpr uint32_t VSPLIT_MAX_B = 16;
+
+__global__ void __launch_bounds__(64) k_vshift(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][SPLIT_S]*/) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  xyzz a = xyzz_from_affine(ld_affine(pts + (size_t)i * 64));
+  st_xyzz(&sh[(size_t)i * SPLIT_S], a);
+#pragma unroll 1
+  for (int s = 1; s < SPLIT_S; s++) {
+#pragma unroll 1
+    for (int b = 0; b < SPLIT_W; b++) a = xyzz_dbl(a);
+    st_xyzz(&sh[(size_t)i * SPLIT_S + s], a);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_round_split(VDims d, uint32_t round, const uint8_t* __restrict__ xk,
+                                                   u256* __restrict__ xk_m, u256* __restrict__ xkinv_m,
+                                                   const xyzz* __restrict__ sh /*[2k][B][SPLIT_S]*/,
+                                                   xyzz* __restrict__ tab /*[B][15][64]*/, uint8_t* __restrict__ acc_aff,
+                                                   uint8_t* __restrict__ host_out, uint8_t* __restrict__ host_txt) {
+  const uint32_t p = blockIdx.x;
+  const int s = threadIdx.x;
+  const size_t B = d.B;
+  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
+  u256 xinv = Fr::inv(x);
+  u256 x2 = Fr::sqr(x);
+  xyzz acc = xyzz_inf();
+  if (s < SPLIT_S) {
+    auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s], v); };
+    auto load = [&](int e) { return ld_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s]); };
+    acc = glv_split_lane(Fr::from_mont(x2), Fr::from_mont(Fr::sqr(xinv)),
+                         ld_xyzz(&sh[((size_t)round * B + p) * SPLIT_S + s]),
+                         ld_xyzz(&sh[((size_t)(d.k + round) * B + p) * SPLIT_S + s]), s, store, load);
+  }
+  acc = wave_sum(acc);  // lanes >= SPLIT_S hold the identity
+  if (s == 0) {
+    stm(xk_m, (size_t)round * B + p, x2);
+    stm(xkinv_m, (size_t)round * B + p, xinv);
+    acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
+    affine out = xyzz_to_affine(acc);
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+    if (host_txt) {
+      uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
+      u256_to_dec_record(out.x, wx);
+      u256_to_dec_record(out.y, wy);
+      uint4* t = (uint4*)(host_txt + (size_t)p * 2 * DEC_REC);
+#pragma unroll
+      for (int i = 0; i < DEC_REC_WORDS / 4; i++) {
+        t[i] = make_uint4(wx[4 * i], wx[4 * i + 1], wx[4 * i + 2], wx[4 * i + 3]);
+        t[DEC_REC_WORDS / 4 + i] = make_uint4(wy[4 * i], wy[4 * i + 1], wy[4 * i + 2], wy[4 * i + 3]);
+      }
+    }
+  }
+}
+
 // mkOtherExponents (Verifier.hs:55-73): s_i = s0 * prod_{bit j of i} x_{k-1-j}^2, s0 = prod_k x_k^-1 (challenges are
 // listed last round first, so bit 0 pairs with the LAST round).  The index is split into its low kl = k/2 bits
 // and the rest: s_i = lo[i & (2^kl - 1)] * hi[i >> kl], with s0 folded into lo.  Thread per proof: both
@@ -616,7 +677,12 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
     size_t cnt = (size_t)2 * d.k * B * 2;
     hipLaunchKernelGGL(k_dec_numbers, VB_GRID_ON(cnt, vb->aux), vb->pts + (size_t)VP_L0 * B * 64, (uint32_t)cnt, lr_text);
   }
-  hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
+  if (vb->split) {
+    const uint32_t cnt = 2 * d.k * d.B;
+    hipLaunchKernelGGL(k_vshift, dim3((cnt + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_L0 * B * 64, cnt, vb->rsh);
+  } else {
+    hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
+  }
   BP_TRY(hipGetLastError());
   vb->tab_pending = true;
   return BP_OK;
@@ -693,7 +759,10 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   // The two inversions of a round are per lane: the kernel is a latency chain the host waits for, and sharing
   // them across the workgroup (batchinv.h) lengthens it (1.58 -> 1.71 ms).  BP_ROUND_BATCHINV=1 selects the shared form.
   static const bool round_batch = getenv("BP_ROUND_BATCHINV") && atoi(getenv("BP_ROUND_BATCHINV")) != 0;
-  if (round_batch)
+  if (vb->split)
+    hipLaunchKernelGGL(k_round_split, dim3(d.B), dim3(64), 0, vb->stream, d, round, xin, vb->xk_m, vb->xkinv_m, vb->rsh,
+                       vb->rsplit_tab, vb->acc_aff, direct, vb->direct_host ? out_text : nullptr);
+  else if (round_batch)
     hipLaunchKernelGGL(k_round<true>, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct,
                        vb->direct_host ? out_text : nullptr);
   else
@@ -819,6 +888,11 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->rtx = c.take<xyzz>((size_t)11 * (d.k ? d.k : 1) * B);
     vb->rpre = c.take<u256>((size_t)11 * (d.k ? d.k : 1) * B);
     vb->rtab = c.take<uint8_t>((size_t)15 * (d.k ? d.k : 1) * B * 64);
+    {
+      const size_t sb = B <= VSPLIT_MAX_B ? B : 1;
+      vb->rsh = c.take<xyzz>((size_t)2 * (d.k ? d.k : 1) * sb * SPLIT_S);
+      vb->rsplit_tab = c.take<xyzz>(sb * 15 * 64);
+    }
     return c.off;
   };
   size_t need = carve(nullptr);
@@ -827,6 +901,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   vb->t_pending = false;
   vb->tab_pending = false;
   vb->begun_complete = false;
+  vb->split = batch <= VSPLIT_MAX_B && d.k > 0 && !(getenv("BP_NO_SPLIT") && atoi(getenv("BP_NO_SPLIT")) != 0);
   hipError_t e = hipSuccess;
   vb->done = nullptr;
   e = hipEventCreateWithFlags(&vb->done, hipEventDisableTiming);
