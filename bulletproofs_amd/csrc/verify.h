@@ -59,7 +59,7 @@ struct bp_vbatch {
   bp::u256* rpre;
   // small batches (B <= 16): the rounds run through eight lanes per proof on shifted forms of L_r, R_r
   bool split;
-  bp::xyzz *rsh, *rsplit_tab;
+  bp::xyzz *rsh, *rsplit_tab, *fpart;  // fpart: workgroup sums of the lane-per-term fixed-base kernel
   uint32_t nt1, nt3a, nt3b, npts;
   int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
   // buffers of the *_async calls are pinned host memory: kernels read challenges from and store results to them directly

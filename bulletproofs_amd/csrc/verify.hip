@@ -53,7 +53,7 @@ __device__ __forceinline__ void put_digits(uint32_t* dig, uint32_t term, const V
 // thread per proof: challenges -> Montgomery constants, y^-i ladder, z powers, delta
 __global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restrict__ chal /*[4][B][32]*/,
                                                u256* __restrict__ cst, u256* __restrict__ ypowinv /*[nm][B]*/,
-                                               u256* __restrict__ zpow /*[m+3][B]*/) {
+                                               u256* __restrict__ zpow /*[m+3][B]*/, bool ladder) {
   __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   size_t B = d.B;
@@ -73,13 +73,29 @@ __global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restri
   stm(cst, C_YINV * B + p, yinv);
   stm(cst, C_X2 * B + p, Fr::sqr(x));
   // y^-i and sum_i y^i, i < nm   (powerVector y nm; RangeProof/Internal.hs:154)
-  u256 cur = Fr::one(), ycur = Fr::one(), ysum = u256_zero();
-  for (uint32_t i = 0; i < d.nm; i++) {
-    stm(ypowinv, (size_t)i * B + p, cur);
-    cur = Fr::mul(cur, yinv);
-    // powerVector's 0^0 = 0 special case (Utils.hs:50-52) only matters for y = 0
-    ysum = Fr::add(ysum, ycur);
-    ycur = Fr::mul(ycur, y);
+  u256 ysum = u256_zero();
+  if (ladder) {
+    u256 cur = Fr::one(), ycur = Fr::one();
+    for (uint32_t i = 0; i < d.nm; i++) {
+      stm(ypowinv, (size_t)i * B + p, cur);
+      cur = Fr::mul(cur, yinv);
+      // powerVector's 0^0 = 0 special case (Utils.hs:50-52) only matters for y = 0
+      ysum = Fr::add(ysum, ycur);
+      ycur = Fr::mul(ycur, y);
+    }
+  } else {
+    // few proofs, long vectors: k_vprep0_pow fills y^-i in parallel; the sum in closed form,
+    // (y^nm - 1) / (y - 1), nm a power of two (the same residue as the term-by-term sum; y = 1 gives nm)
+    u256 ynm = y;
+    for (uint32_t j = 0; j < d.k; j++) ynm = Fr::sqr(ynm);
+    u256 ym1 = Fr::sub(y, Fr::one());
+    if (u256_is_zero(ym1)) {
+      u256 nmv = u256_zero();
+      nmv.v[0] = d.nm;
+      ysum = Fr::to_mont(nmv);
+    } else {
+      ysum = Fr::mul(Fr::sub(ynm, Fr::one()), Fr::inv(ym1));
+    }
   }
   // z^e, e = 0..m+2
   u256 zc = Fr::one();
@@ -99,6 +115,20 @@ __global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restri
   }
   u256 delta = Fr::sub(Fr::mul(Fr::sub(z, z2), ysum), Fr::mul(zs, tn1));
   stm(cst, C_DELTA * B + p, delta);
+}
+
+// thread per (i, p): y^-i by square-and-multiply over the bits of i (small batches; see k_vprep0)
+__global__ void __launch_bounds__(256) k_vprep0_pow(VDims d, const u256* __restrict__ cst, u256* __restrict__ ypowinv) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t B = d.B;
+  if (t >= (size_t)d.nm * B) return;
+  uint32_t i = (uint32_t)(t / B), p = (uint32_t)(t % B);
+  u256 base = ldm(cst, C_YINV * B + p), r = Fr::one();
+  for (uint32_t e = i; e; e >>= 1) {
+    if (e & 1u) r = Fr::mul(r, base);
+    base = Fr::sqr(base);
+  }
+  stm(ypowinv, (size_t)i * B + p, r);
 }
 
 // thread per (i, p): digits of c_i = z + z^(i/n + 2) * 2^(i%n) * y^-i for base H_i;
@@ -244,6 +274,39 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
     acc = xyzz_add(acc, o);
   }
   if (live && sub == 0) st_xyzz(&acc_out[p], acc);
+}
+
+// Small batches with many terms: 64 lanes per proof leave hundreds of additions per lane.  One lane per term
+// instead (all windows of its digits), workgroup sums into part[p][block], k_fixed_sum adds the workgroups.
+template <int WB>
+__global__ void __launch_bounds__(256) k_fixed_terms(uint32_t B, uint32_t nterms, const uint32_t* __restrict__ dig,
+                                                    const uint32_t* __restrict__ term_base, const uint8_t* __restrict__ table,
+                                                    xyzz* __restrict__ part /*[B][gridDim.x]*/) {
+  constexpr int W = fb_windows(WB), E = fb_entries(WB), DW = fb_dwords(WB), SLOT = fb_slot_bits(WB), PER = 32 / SLOT;
+  __shared__ xyzz red[4];
+  const uint32_t p = blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
+  xyzz acc = xyzz_inf();
+  if (t < nterms) {
+    const size_t row0 = (size_t)term_base[t] * W * E;
+#pragma unroll 1
+    for (int w = 0; w < W; w++) {
+      uint32_t word = dig[((size_t)t * DW + (w / PER)) * B + p];
+      uint32_t code = SLOT == 32 ? word : ((word >> ((SLOT * (w % PER)) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
+      if (code == 0) continue;
+      bool neg;
+      uint32_t mag = fb_decode<WB>(code, neg);
+      bucket_add(acc, ld_affine(table + (row0 + (size_t)w * E + (mag - 1)) * 64), neg);
+    }
+  }
+  xyzz sum = block_sum(acc, red);
+  if (threadIdx.x == 0) st_xyzz(&part[(size_t)p * gridDim.x + blockIdx.x], sum);
+}
+__global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk, const xyzz* __restrict__ part, xyzz* __restrict__ acc_out) {
+  const uint32_t p = blockIdx.x;
+  xyzz acc = xyzz_inf();
+  for (uint32_t i = threadIdx.x; i < nblk; i += 64u) acc = xyzz_add(acc, ld_xyzz(&part[(size_t)p * nblk + i]));
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) st_xyzz(&acc_out[p], acc);
 }
 
 // ---- variable-base terms: GLV halves + joint (Straus) tables in global memory (glv.h) ----------
@@ -616,6 +679,20 @@ static inline void launch_fixed(bp_vbatch* vb, size_t nthreads, uint32_t nterms,
                                 const uint32_t* tb, xyzz* acc, hipStream_t strm = nullptr) {
   const uint8_t* table = vb->ctx->d_table;
   if (!strm) strm = vb->stream;
+  if (vb->split && nterms >= 512 && lpp > 1) {  // few proofs, many terms: one lane per term, two launches
+    const uint32_t nblk = (nterms + 255) / 256;
+    dim3 grid(nblk, vb->d.B), block(256);
+    if (vb->d.wb == 20)
+      hipLaunchKernelGGL(k_fixed_terms<20>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+    else if (vb->d.wb == 16)
+      hipLaunchKernelGGL(k_fixed_terms<16>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+    else if (vb->d.wb == 12)
+      hipLaunchKernelGGL(k_fixed_terms<12>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+    else
+      hipLaunchKernelGGL(k_fixed_terms<8>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+    hipLaunchKernelGGL(k_fixed_sum, dim3(vb->d.B), dim3(64), 0, strm, nblk, vb->fpart, acc);
+    return;
+  }
   if (vb->d.wb == 20)
     hipLaunchKernelGGL(k_fixed_multiexp<20>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
   else if (vb->d.wb == 16)
@@ -712,7 +789,9 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
     BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
     chal = vb->chal;
   }
-  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow);
+  const bool ladder = !(vb->split && d.nm >= 256);
+  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow, ladder);
+  if (!ladder) hipLaunchKernelGGL(k_vprep0_pow, VB_GRID((size_t)d.nm * B), d, vb->cst, vb->ypowinv);
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   uint32_t lpp = vbatch_lpp(d.B);
   prof_begin(vb, 0, vb->nt1);
@@ -892,6 +971,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
       const size_t sb = B <= VSPLIT_MAX_B ? B : 1;
       vb->rsh = c.take<xyzz>((size_t)2 * (d.k ? d.k : 1) * sb * SPLIT_S);
       vb->rsplit_tab = c.take<xyzz>(sb * 15 * 64);
+      vb->fpart = c.take<xyzz>(sb * ((vb->nt3a + 255) / 256));
     }
     return c.off;
   };

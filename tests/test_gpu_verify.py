@@ -135,6 +135,21 @@ def test_derive_generators_matches_oracle(engine):
     engine.set_generators(o.gs(128), o.hs(128), o.h())  # restore for the other tests
 
 
+def test_small_batch_long_vectors(engine):
+    """A few proofs with nm = 256 take the small-batch paths of the verifier (y^-i by square-and-multiply and
+    the closed-form power sum, one lane per term in the fixed-base sums, rounds through eight lanes per proof):
+    computeLRCommitment, every mkChallenges accumulator and the verdicts equal the oracle's."""
+    rng = random.Random(4242)
+    n, m = 64, 4
+    engine.derive_generators(n * m)
+    vs = [(rng.randrange(0, 2**n), rng.randrange(1, R)) for _ in range(m)]
+    pr = engine.prove(n, vs, *o.draw_blinders(rng, n * m))
+    vc = [o.commit(v, b) for v, b in vs]
+    bad = dict(pr, t=(pr["t"] + 1) % R)
+    assert run_batch(engine, n, m, [pr, bad], [vc, vc]) == [True, False]
+    engine.set_generators(o.gs(128), o.hs(128), o.h())  # restore for the other tests
+
+
 def test_generator_table_file(engine, tmp_path):
     """bp_generators_save / bp_generators_load: the file holds exactly the oracle's h, gs, hs (Utils.hs:14-25) with a
     checksum; a loaded table verifies proofs like a derived one; corrupted and off-curve files are refused."""
