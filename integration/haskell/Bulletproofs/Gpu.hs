@@ -18,6 +18,7 @@ import qualified Data.ByteString.Internal as BI
 import qualified Data.ByteString.Unsafe as BU
 import Data.Bits (shiftL, shiftR, (.|.))
 import Foreign
+import Foreign.C.String (CString)
 import Foreign.C.Types
 import System.IO.Unsafe (unsafePerformIO)
 import Control.Monad.Random (MonadRandom, getRandomR)
@@ -35,6 +36,11 @@ data BpCtx
 
 foreign import ccall safe "bp_ctx_create"        c_ctx_create   :: Ptr (Ptr BpCtx) -> CInt -> IO CInt
 foreign import ccall safe "bp_generators_derive" c_gens_derive  :: Ptr BpCtx -> Word32 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> IO CInt
+-- generator CAFs from a file written by benchmarks/gen_tables.py / bp_generators_save (checked on load), and the
+-- device's decimal `show` digits (80-byte records) for a transcript kept in Haskell
+foreign import ccall safe "bp_generators_load"   c_gens_load    :: Ptr BpCtx -> CString -> IO CInt
+foreign import ccall safe "bp_generators_save"   c_gens_save    :: Ptr BpCtx -> CString -> IO CInt
+foreign import ccall safe "bp_show_numbers"      c_show_numbers :: Ptr BpCtx -> Ptr Word8 -> CSize -> Ptr Word8 -> IO CInt
 foreign import ccall safe "bp_msm"               c_msm          :: Ptr BpCtx -> Ptr Word8 -> Ptr Word8 -> CSize -> Ptr Word8 -> IO CInt
 foreign import ccall safe "bp_add_two_mul"       c_add_two_mul  :: Ptr BpCtx -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> CSize -> Ptr Word8 -> IO CInt
 foreign import ccall safe "bp_upper_bound_bits"  c_ub_bits      :: Ptr Word8 -> CSize -> Ptr Word32 -> IO CInt
