@@ -544,6 +544,42 @@ __global__ void __launch_bounds__(64) k_round_split(VDims d, uint32_t round, con
   }
 }
 
+// stage 1 tail of a small batch: P = acc1 + x*S + A with x*S through the eight lanes (S shifted by k_vshift)
+__global__ void __launch_bounds__(64) k_stage1_tail_split(VDims d, const uint8_t* __restrict__ pts, const u256* __restrict__ cst,
+                                                         const xyzz* __restrict__ acc1, const xyzz* __restrict__ shS /*[B][SPLIT_S]*/,
+                                                         xyzz* __restrict__ tab /*[B][15][64]*/, uint8_t* __restrict__ acc_aff,
+                                                         uint8_t* __restrict__ host_out, uint8_t* __restrict__ host_txt) {
+  const uint32_t p = blockIdx.x;
+  const int s = threadIdx.x;
+  const size_t B = d.B;
+  xyzz acc = xyzz_inf();
+  if (s < SPLIT_S) {
+    auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s], v); };
+    auto load = [&](int e) { return ld_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s]); };
+    acc = glv_split_lane(Fr::from_mont(ldm(cst, C_X * B + p)), u256_zero(), ld_xyzz(&shS[(size_t)p * SPLIT_S + s]),
+                         xyzz_inf(), s, store, load);
+  }
+  acc = wave_sum(acc);
+  if (s == 0) {
+    acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
+    acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
+    affine out = xyzz_to_affine(acc);
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+    if (host_txt) {
+      uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
+      u256_to_dec_record(out.x, wx);
+      u256_to_dec_record(out.y, wy);
+      uint4* t = (uint4*)(host_txt + (size_t)p * 2 * DEC_REC);
+#pragma unroll
+      for (int i = 0; i < DEC_REC_WORDS / 4; i++) {
+        t[i] = make_uint4(wx[4 * i], wx[4 * i + 1], wx[4 * i + 2], wx[4 * i + 3]);
+        t[DEC_REC_WORDS / 4 + i] = make_uint4(wy[4 * i], wy[4 * i + 1], wy[4 * i + 2], wy[4 * i + 3]);
+      }
+    }
+  }
+}
+
 // mkOtherExponents (Verifier.hs:55-73): s_i = s0 * prod_{bit j of i} x_{k-1-j}^2, s0 = prod_k x_k^-1 (challenges are
 // listed last round first, so bit 0 pairs with the LAST round).  The index is split into its low kl = k/2 bits
 // and the rest: s_i = lo[i & (2^kl - 1)] * hi[i >> kl], with s0 folded into lo.  Thread per proof: both
@@ -756,6 +792,9 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
   }
   if (vb->split) {
     const uint32_t cnt = 2 * d.k * d.B;
+    // S first (stage 1 needs it), then the rows L_r, R_r
+    hipLaunchKernelGGL(k_vshift, dim3((d.B + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_S * B * 64, d.B,
+                       vb->rsh + (size_t)cnt * SPLIT_S);
     hipLaunchKernelGGL(k_vshift, dim3((cnt + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_L0 * B * 64, cnt, vb->rsh);
   } else {
     hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
@@ -801,8 +840,18 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   // other (measured: benchmarks/concurrency_test3.hip); with pinned outputs the kernel stores its
   // result to host memory itself.
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
-  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
-                     vb->direct_host ? out_text : nullptr);
+  if (vb->split) {
+    // the shifted forms come from the side stream (launched at prepare, ~0.6 ms of doublings): host-side join,
+    // which also covers the rounds' needs
+    if (vb->tab_pending && vb->aux != vb->stream) BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->tab_pending = false;
+    hipLaunchKernelGGL(k_stage1_tail_split, dim3(d.B), dim3(64), 0, vb->stream, d, vb->pts, vb->cst, vb->acc1,
+                       vb->rsh + (size_t)2 * d.k * B * SPLIT_S, vb->rsplit_tab, vb->acc_aff, direct,
+                       vb->direct_host ? out_text : nullptr);
+  } else {
+    hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
+                       vb->direct_host ? out_text : nullptr);
+  }
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
@@ -969,7 +1018,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->rtab = c.take<uint8_t>((size_t)15 * (d.k ? d.k : 1) * B * 64);
     {
       const size_t sb = B <= VSPLIT_MAX_B ? B : 1;
-      vb->rsh = c.take<xyzz>((size_t)2 * (d.k ? d.k : 1) * sb * SPLIT_S);
+      vb->rsh = c.take<xyzz>(((size_t)2 * (d.k ? d.k : 1) + 1) * sb * SPLIT_S);  // L_r, R_r rows, then S
       vb->rsplit_tab = c.take<xyzz>(sb * 15 * 64);
       vb->fpart = c.take<xyzz>(sb * ((vb->nt3a + 255) / 256));
     }
