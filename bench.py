@@ -144,8 +144,8 @@ def msm_probe(eng, logn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU")
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=0)
