@@ -43,6 +43,7 @@ SYMBOLS = {
     "bp_last_error": (ctypes.c_char_p, [_vp]),
     "bp_ctx_sync": (_int, [_vp]),
     "bp_ctx_stream": (_vp, [_vp]),
+    "bp_ctx_queue_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "bp_ctx_profile": (_int, [_vp, _int]),
     "bp_ctx_profile_read": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                                    ctypes.POINTER(ctypes.c_double)]),
@@ -219,6 +220,13 @@ class Engine:
 
     def msm_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
         self._check(self.lib.bp_msm_dev(self.h, d_scalars, d_points, n, window_bits, d_out), "bp_msm_dev")
+
+    def queue_info(self):
+        """-> (GPU_MAX_HW_QUEUES of the process or 0, pool streams, streams measured to run concurrently)."""
+        a, b, c = _int(), _int(), _int()
+        self._check(self.lib.bp_ctx_queue_info(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+                    "bp_ctx_queue_info")
+        return a.value, b.value, c.value
 
     # -- list-of-ints conveniences (tests) -----------------------------------------
     def mul(self, points, scalars):

@@ -75,6 +75,7 @@ static void build_stream_pool(bp_ctx* ctx) {
     for (int g : ctx->sgroup) fprintf(stderr, " %d", g);
     fprintf(stderr, " }\n");
   }
+  ctx->sgroup_probed = ctx->sgroup.size() >= 2;
   if (ctx->sgroup.size() < 2) {  // nothing overlaps (e.g. 4 hardware queues): any streams will do
     ctx->sgroup.clear();
     for (size_t i = 0; i < ctx->spool.size(); i++) ctx->sgroup.push_back((int)i);
@@ -108,12 +109,10 @@ int bp_version(void) { return 100; }
 int bp_ctx_create(bp_ctx** out, int device) {
   if (!out) return BP_ERR_ARG;
   *out = nullptr;
-  // more hardware queues than HIP's default of 4, so that chunk streams can share a pipe (see above);
-  // only effective if the HIP runtime has not been initialised yet; BP_KEEP_HW_QUEUES leaves the setting alone
-  if (!getenv("BP_KEEP_HW_QUEUES")) {
-    const char* cur = getenv("GPU_MAX_HW_QUEUES");
-    if (!cur || atoi(cur) < 8) setenv("GPU_MAX_HW_QUEUES", "16", 1);
-  }
+  // The chunk streams of the batch verifier overlap best with more hardware queues than HIP's default of 4
+  // (GPU_MAX_HW_QUEUES=16, read by the HIP runtime when it initialises).  The library does not touch the process
+  // environment: the host application sets the variable before HIP starts, and
+  // bp_ctx_queue_info reports what the stream-pool probe found.
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return BP_ERR_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return BP_ERR_DEVICE;
@@ -153,6 +152,19 @@ int bp_ctx_sync(bp_ctx* ctx) {
 }
 
 void* bp_ctx_stream(bp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int bp_ctx_queue_info(bp_ctx* ctx, int* hw_queues_env, int* pool_streams, int* concurrent_streams) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_TRY(hipSetDevice(ctx->device));
+  if (ctx->spool.empty()) bp::build_stream_pool(ctx);
+  if (hw_queues_env) {
+    const char* cur = getenv("GPU_MAX_HW_QUEUES");
+    *hw_queues_env = cur ? atoi(cur) : 0;
+  }
+  if (pool_streams) *pool_streams = (int)ctx->spool.size();
+  if (concurrent_streams) *concurrent_streams = ctx->sgroup_probed ? (int)ctx->sgroup.size() : 0;
+  return BP_OK;
+}
 
 int bp_ctx_profile(bp_ctx* ctx, int enable) {
   if (!ctx) return BP_ERR_ARG;

@@ -68,6 +68,7 @@ struct bp_ctx {
   // streams for the batch verifier's chunks: a set that the hardware runs concurrently (ctx.hip)
   std::vector<hipStream_t> spool;
   std::vector<int> sgroup;  // indices into spool that overlap with each other
+  bool sgroup_probed = false;  // the probe found a concurrent set (else sgroup = every stream)
   size_t spool_next = 0;
   size_t aux_next = 0;
   int fb_wbits = 8;            // window width of d_table (8, 12 or 16), chosen in bp_ctx_set_generators

@@ -394,6 +394,8 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
     } else if (stage[pick] <= k) {
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;  // completed already: folds the profiling events in
       uint32_t r = stage[pick] - 1;
+      // round 0 hashes the text of L_0, R_0 that k_dec_numbers wrote on the SIDE stream: join it first
+      if (r == 0 && (rc = vbatch_join_side(ch.vb)) != BP_OK) return rc;
       hashR(ch, r);
       TRACE("hashR", pick, r, t_h);
       if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc, ch.acc_txt)) != BP_OK) return rc;

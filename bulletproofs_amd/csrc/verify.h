@@ -87,6 +87,8 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
 int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
 int vbatch_wait(bp_vbatch* vb);
+// joins the side stream of vbatch_prepare_async (L_r, R_r text, round tables); call before hashing round 0
+int vbatch_join_side(bp_vbatch* vb);
 // has everything enqueued by the last *_async call completed?  (non-blocking)
 bool vbatch_ready(bp_vbatch* vb);
 }  // namespace bp

@@ -932,6 +932,18 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
   return BP_OK;
 }
 
+// Host-side join of the pass's side work (vbatch_prepare_async: the decimal text of L_r, R_r and the rounds' joint
+// tables, on vb->aux).  The caller must do this BEFORE it reads lr_text for the round-0 transcript: vbatch_wait only
+// covers vb->stream, and the text is written on the side stream.
+int vbatch_join_side(bp_vbatch* vb) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->tab_pending) {
+    if (vb->aux != vb->stream) BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->tab_pending = false;
+  }
+  return BP_OK;
+}
+
 // A stream query, not an event: recording an event behind the kernels puts a marker packet into the queue,
 // and such packets were measured to break the overlap between chunk streams just like copy commands do.
 bool vbatch_ready(bp_vbatch* vb) { return hipStreamQuery(vb->stream) == hipSuccess; }

@@ -57,6 +57,13 @@ int bp_ctx_sync(bp_ctx* ctx);
 /* The context's hipStream_t, as an opaque pointer. */
 void* bp_ctx_stream(bp_ctx* ctx);
 
+/* What the context's stream-pool probe found: the value of GPU_MAX_HW_QUEUES the process runs under (0 = unset,
+ * HIP's default of 4 applies), the pool size, and how many of the pool's streams were measured to run kernels
+ * side by side (0 = none found: the batch verifier's chunks then serialise and a step is ~15 % slower).  The
+ * library never changes the environment; the host sets GPU_MAX_HW_QUEUES=16 before HIP initialises
+ * (INTEGRATION.md).  Any pointer may be NULL.  No counterpart in the reference. */
+int bp_ctx_queue_info(bp_ctx* ctx, int* hw_queues_env, int* pool_streams, int* concurrent_streams);
+
 /* Kernel timing for the benchmark's roofline line: when enabled, the two dominant kernels are
  * bracketed with HIP events on the stream they are launched on.  kernel 0 = k_fixed_multiexp
  * (batch verifier), 1 = k_light (MSM bucket accumulation).  Returns the accumulated device
