@@ -116,6 +116,8 @@ int bp_ctx_create(bp_ctx** out, int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return BP_ERR_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return BP_ERR_DEVICE;
+  // this device's copy of the MSM's static scratch array (bp_msm_dev_static), resolved once per device
+  if (bp::msm_static_init(device) != BP_OK) return BP_ERR_DEVICE;
   bp_ctx* ctx = new bp_ctx();
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -109,6 +109,12 @@ hipStream_t ctx_chunk_stream(bp_ctx* ctx);
 hipStream_t ctx_aux_stream(bp_ctx* ctx);
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz);
+// The same over the file-scope scratch array of msm.hip instead of ctx->msm_ws (bp_msm_dev_static): calls no
+// hipMalloc / hipFree.  msm_static_init(device) resolves that device's copy of the array once (bp_ctx_create calls it
+// with the device current); msm_static_bytes() is its size.
+int msm_static_init(int device);
+size_t msm_static_bytes();
+int msm_run_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out);
 // ipp.hip (device pointers, asynchronous on ctx->stream)
 // One batch of two-scalar linear combinations: out[i] = ka*a[i] + kb*b[i] (+ c[i] when c != null), i < n.
 // sa / sb, when non-null, give per-lane canonical scalars (32 B each) instead of the shared ka / kb.

@@ -15,6 +15,7 @@
 //   7 k_window_sum    workgroup tree reduction of the segment values of one window
 //   8 k_final         Horner over the windows + affine normalisation
 #include <stdlib.h>
+#include <mutex>
 #include "engine.h"
 #include "devio.h"
 #include "glv.h"
@@ -437,9 +438,35 @@ int msm_direct_multi(bp_ctx* ctx, const uint8_t* d_scalars, const uint8_t* d_poi
 }
 
 // -------------------------------------------------------------------------------------------------
-int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
-            void* d_out_xyzz) {
+// The MSM's device workspace: the context's grow-only buffer (fixed == nullptr), or a caller-provided block of
+// `fixed_bytes` that is never grown (bp_msm_dev_static: no allocation on that path).
+struct MsmWsSource {
+  void* fixed;
+  size_t fixed_bytes;
+};
+static int msm_ws_get(bp_ctx* ctx, const MsmWsSource& src, size_t need, void** out) {
+  if (src.fixed) {
+    if (need > src.fixed_bytes) {
+      ctx->err = "bp_msm_dev_static: this n / window_bits needs more than the static scratch array holds";
+      return BP_ERR_ARG;
+    }
+    *out = src.fixed;
+    return BP_OK;
+  }
+  if (ctx->msm_ws.reserve(need) != 0) {
+    ctx->err = "bp_msm: workspace allocation failed";
+    return BP_ERR_NOMEM;
+  }
+  *out = ctx->msm_ws.p;
+  return BP_OK;
+}
+
+static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalars, const void* d_points, size_t n,
+                      int c_override, void* d_out_affine, void* d_out_xyzz) {
   hipStream_t st = ctx->stream;
+  const bool profile = ctx->profile && !wsrc.fixed;  // event creation allocates: never on the static path
+  void* ws = nullptr;
+  int rc;
   if (n == 0) {
     hipLaunchKernelGGL(k_store_inf, dim3(1), dim3(64), 0, st, (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
     BP_TRY(hipGetLastError());
@@ -451,11 +478,8 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   }
   if (c_override <= 0 && n <= msm_direct_max()) {
     uint32_t nblk = (uint32_t)((n + 255) / 256);
-    if (ctx->msm_ws.reserve((size_t)nblk * sizeof(xyzz)) != 0) {
-      ctx->err = "bp_msm: workspace allocation failed";
-      return BP_ERR_NOMEM;
-    }
-    xyzz* partial = (xyzz*)ctx->msm_ws.p;
+    if ((rc = msm_ws_get(ctx, wsrc, (size_t)nblk * sizeof(xyzz), &ws)) != BP_OK) return rc;
+    xyzz* partial = (xyzz*)ws;
     SegN sn = {{(uint32_t)n, 0, 0, 0}};
     hipLaunchKernelGGL(k_direct_terms, dim3(nblk), dim3(256), 0, st, (const uint8_t*)d_scalars, (const uint8_t*)d_points,
                        nblk, sn, partial);
@@ -504,11 +528,8 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
     return cv.off;
   };
   size_t need = carve(nullptr);
-  if (ctx->msm_ws.reserve(need) != 0) {
-    ctx->err = "bp_msm: workspace allocation failed";
-    return BP_ERR_NOMEM;
-  }
-  carve(ctx->msm_ws.p);
+  if ((rc = msm_ws_get(ctx, wsrc, need, &ws)) != BP_OK) return rc;
+  carve(ws);
   size_t zero_bytes = (size_t)((char*)(bins + 2 * NBINS + 8) - (char*)hist);
   BP_TRY(hipMemsetAsync(hist, 0, zero_bytes, st));
 
@@ -527,7 +548,7 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
   hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
   hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
-  if (ctx->profile) {  // the previous call's pair has completed on this in-order stream or is read after a sync
+  if (profile) {  // the previous call's pair has completed on this in-order stream or is read after a sync
     if (!ctx->msm_ev[0]) {
       BP_TRY(hipEventCreate(&ctx->msm_ev[0]));
       BP_TRY(hipEventCreate(&ctx->msm_ev[1]));
@@ -543,7 +564,7 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   }
   hipLaunchKernelGGL(k_light, dim3((nbt32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs,
                      sorted, order, nbt32, glv, buckets);
-  if (ctx->profile) {
+  if (profile) {
     BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
     ctx->prof_pending_light = true;
     ctx->prof_madds[1] += (double)wn;
@@ -560,6 +581,47 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, wsum, pl, (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
   BP_TRY(hipGetLastError());
   return BP_OK;
+}
+
+int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
+            void* d_out_xyzz) {
+  return msm_run_ws(ctx, MsmWsSource{nullptr, 0}, d_scalars, d_points, n, c_override, d_out_affine, d_out_xyzz);
+}
+
+// ---- the entry point that allocates nothing (include/bpgpu.h: bp_msm_dev_static) -------------------------------
+// Its workspace is this file-scope array: every GPU the library runs on holds one copy until the process ends.  In
+// host code the NAME `scratch` is only a handle for hipGetSymbolAddress - never pass it to a kernel or a memset; the
+// per-device address comes from msm_static_init (called by bp_ctx_create with the device current) and is what the
+// kernels receive, exactly as they receive ctx->msm_ws.p on the allocating path.
+constexpr size_t MSM_STATIC_BYTES = (size_t)32 << 20;
+static __device__ __align__(256) unsigned char scratch[MSM_STATIC_BYTES];
+constexpr int MSM_STATIC_MAX_DEV = 64;
+static void* g_scratch_ptr[MSM_STATIC_MAX_DEV];  // per device: each GPU has its own copy at its own address
+static std::mutex g_scratch_mu;
+
+int msm_static_init(int device) {
+  if (device < 0 || device >= MSM_STATIC_MAX_DEV) return BP_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[device]) return BP_OK;
+  void* ptr = nullptr;
+  if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return BP_ERR_DEVICE;
+  g_scratch_ptr[device] = ptr;
+  return BP_OK;
+}
+
+size_t msm_static_bytes() { return MSM_STATIC_BYTES; }
+
+int msm_run_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out) {
+  void* ptr = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (ctx->device >= 0 && ctx->device < MSM_STATIC_MAX_DEV) ptr = g_scratch_ptr[ctx->device];
+  }
+  if (!ptr) {
+    ctx->err = "bp_msm_dev_static: the scratch array of this device was not resolved at bp_ctx_create";
+    return BP_ERR_STATE;
+  }
+  return msm_run_ws(ctx, MsmWsSource{ptr, MSM_STATIC_BYTES}, d_scalars, d_points, n, c_override, d_out, nullptr);
 }
 
 }  // namespace bp

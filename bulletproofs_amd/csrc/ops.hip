@@ -244,6 +244,16 @@ int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t 
   return msm_run(ctx, d_scalars, d_points, n, window_bits, d_out, nullptr);
 }
 
+int bp_msm_dev_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
+                      void* d_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(d_out && (n == 0 || (d_scalars && d_points)), "null pointer");
+  BP_REQUIRE(window_bits >= 0 && window_bits <= 16, "window_bits must be 0 (auto) or 1..16");
+  BP_REQUIRE(n <= BP_MSM_STATIC_MAX_N, "bp_msm_dev_static: n exceeds BP_MSM_STATIC_MAX_N (use bp_msm_dev)");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_run_static(ctx, d_scalars, d_points, n, window_bits, d_out);
+}
+
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
   if (!ctx) return BP_ERR_ARG;
   BP_REQUIRE(out && (n == 0 || (scalars && points)), "null pointer");

@@ -108,6 +108,21 @@ int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok)
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
 int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
 
+/* bp_msm_dev_static  bp_msm_dev for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ *                   harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
+ *                   same result bytes, asynchronous on the context's stream; it calls no hipMalloc, hipFree or
+ *                   other allocating routine.  Its workspace (digit codes, bucket lists, histograms, bucket and
+ *                   partial sums) is a 32 MiB static device array that every GPU the library runs on holds
+ *                   until the process ends.  Limits: n <= BP_MSM_STATIC_MAX_N, and a forced window_bits whose
+ *                   workspace exceeds the array is refused (BP_ERR_ARG) - nothing is launched then.  All calls
+ *                   on one GPU share that GPU's array: calls that overlap in time on one GPU (two contexts, two
+ *                   host threads) race; calls on one context's stream are ordered and safe.  Kernel timing
+ *                   (bp_ctx_profile) does not cover this entry point.
+ */
+#define BP_MSM_STATIC_MAX_N 65536u
+int bp_msm_dev_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
+                      void* d_out);
+
 /* ---- generator set ----
  *
  * bp_ctx_set_generators  uploads the reference's generator lists and builds the
