@@ -56,6 +56,9 @@ SYMBOLS = {
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_msm_dev_static": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
+    "bp_fr_vector_op": (_int, [_vp, _int, _u8p, _u8p, ctypes.c_uint32, _u8p]),
+    "bp_rp_polys_selftest": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32] + [_u8p] * 7),
+    "bp_ipp_fold_selftest": (_int, [_vp, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p, ctypes.c_uint32, _u8p, _u8p]),
     "bp_show_numbers": (_int, [_vp, _u8p, _sz, _u8p]),
     "bp_generators_save": (_int, [_vp, ctypes.c_char_p]),
     "bp_generators_load": (_int, [_vp, ctypes.c_char_p]),
@@ -80,6 +83,8 @@ SYMBOLS = {
     "bp_vjob_load": (_int, [_vp, _u8p, _u8p]),
     "bp_vjob_run": (_int, [_vp, _u8p]),
     "bp_ipp_prove": (_int, [_vp, ctypes.c_uint32] + [_u8p] * 10),
+    "bp_ipp_verify": (_int, [_vp, ctypes.c_uint64, _u8p, ctypes.c_uint32, _u8p, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p,
+                             ctypes.c_uint32, _u8p, _u8p, _u8p]),
     "bp_upper_bound_bits": (_int, [_u8p, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "bp_rangeproof_prove": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32] + [_u8p] * 8 + [_int, _u8p, _u8p]),
     "bp_rangeproof_wire_size": (_sz, [ctypes.c_uint32]),
@@ -276,6 +281,40 @@ class Engine:
         self._check(self.lib.bp_field_op(self.h, field, op, enc_scalars(a), enc_scalars(b), n, out), "bp_field_op")
         return dec_scalars(out.raw, n)
 
+    def fr_vector_op(self, op, a, b=None):
+        """bp_fr_vector_op: 0 powerVector (a = (scalar, n)), 1 hadamard, 2 dot."""
+        if op == 0:
+            a, n = a
+            out = ctypes.create_string_buffer(32 * max(n, 1))
+            self._check(self.lib.bp_fr_vector_op(self.h, 0, enc_scalar(a), None, n, out), "bp_fr_vector_op")
+            return dec_scalars(out.raw, n)
+        n = len(a)
+        out = ctypes.create_string_buffer(32 * max(n, 1))
+        self._check(self.lib.bp_fr_vector_op(self.h, op, enc_scalars(a), enc_scalars(b), n, out), "bp_fr_vector_op")
+        return dec_scalars(out.raw, n) if op == 1 else dec_scalar(out.raw[:32])
+
+    def rp_polys(self, n_bits, m, a_l, s_l, s_r, y, z, x):
+        """-> (l0, r0, r1, ls, rs, (t0, t1, t2)) from the range prover's kernels."""
+        nm = n_bits * m
+        out = ctypes.create_string_buffer(32 * (5 * nm + 3))
+        self._check(self.lib.bp_rp_polys_selftest(self.h, n_bits, m, bytes(a_l), enc_scalars(s_l), enc_scalars(s_r),
+                                                  enc_scalar(y), enc_scalar(z), enc_scalar(x), out),
+                    "bp_rp_polys_selftest")
+        v = dec_scalars(out.raw, 5 * nm + 3)
+        return tuple(v[i * nm:(i + 1) * nm] for i in range(5)) + (tuple(v[5 * nm:]),)
+
+    def ipp_fold(self, ls, rs, hscale, ub, xs):
+        """-> (ls', rs', dot, ub*cL, ub*cR, [3][2n+1] scalars) after len(xs) rounds of the prover's witness kernels."""
+        n, r = len(ls), len(xs)
+        nk = n >> r
+        out = ctypes.create_string_buffer(32 * (2 * nk + 3 + 3 * (2 * n + 1)))
+        self._check(self.lib.bp_ipp_fold_selftest(self.h, n, enc_scalars(ls), enc_scalars(rs), enc_scalars(hscale),
+                                                  enc_scalar(ub), r, enc_scalars(xs), out), "bp_ipp_fold_selftest")
+        v = dec_scalars(out.raw, 2 * nk + 3 + 3 * (2 * n + 1))
+        nt = 2 * n + 1
+        sc = v[2 * nk + 3:]
+        return v[:nk], v[nk:2 * nk], v[2 * nk], v[2 * nk + 1], v[2 * nk + 2], [sc[q * nt:(q + 1) * nt] for q in range(3)]
+
     def show_numbers(self, values):
         """Decimal text of 256-bit integers as the verifier's kernels format it for the host transcript."""
         n = len(values)
@@ -329,6 +368,17 @@ class Engine:
                                           enc_scalars(ls), enc_scalars(rs), L, R_, l, r), "bp_ipp_prove")
         return dict(lCommits=dec_points(L.raw, k), rCommits=dec_points(R_.raw, k), l=dec_scalar(l.raw),
                     r=dec_scalar(r.raw))
+
+    def ipp_verify(self, n, gs, hs, u, P, proof):
+        """IPP.verifyProof n (InnerProductBase gs hs u) P proof (InnerProductProof/Verifier.hs:18-38) -> bool."""
+        Ls, Rs = list(proof["lCommits"]), list(proof["rCommits"])
+        k = min(len(Ls), len(Rs))  # zip
+        out = ctypes.create_string_buffer(1)
+        self._check(self.lib.bp_ipp_verify(self.h, n, enc_points(gs), len(gs), enc_points(hs), len(hs), enc_point(u),
+                                           enc_point(P), enc_points(Ls[:k]), enc_points(Rs[:k]), k,
+                                           enc_scalar(proof["l"] % R_ORDER), enc_scalar(proof["r"] % R_ORDER), out),
+                    "bp_ipp_verify")
+        return out.raw[0] != 0
 
     def prove(self, n_bits, vs_and_blindings, s_l, s_r, a_blinding, s_blinding, t1_blinding, t2_blinding,
               checked=True):

@@ -160,6 +160,160 @@ int check_dims(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, uint32_t& n2, ui
   return BP_OK;
 }
 
+// generateProof (ArithmeticCircuit/Prover.hs:21-101) with the O(n) and O(Q n) scalar-field vector work on the device
+// (frvec.hip): the assignment and blinding vectors are uploaded once and stay in HBM through commitBitVector's
+// scalars, zs . W (`vectorMatrixProduct`), computePolynomials, multiplyPoly, evaluatePolynomial and the inner-product
+// recursion.  The host keeps the transcript, zs, the O(Q m) commitment-weight sums and the proof's three scalars.
+int ac_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t n2, uint32_t k, uint32_t q, uint32_t m, const uint8_t* wL,
+                 const uint8_t* wR, const uint8_t* wO, const uint8_t* wV, const uint8_t* a_l, const uint8_t* a_r,
+                 const uint8_t* a_o, const uint8_t* commit_blinders, const uint8_t* blind3, const uint8_t* s_l,
+                 const uint8_t* s_r, const uint8_t* tau5, uint8_t* proof_scalars, uint8_t* proof_points) {
+  const ShowStyle style = (ShowStyle)ctx->show_style;
+  hipStream_t st = ctx->stream;
+  const uint32_t ng = ctx->n_gens;
+  FrDev& f = w.fr;
+  int rc;
+  const Fr4 zero = fr_zero();
+  uint8_t* AI = proof_points;
+  uint8_t* AO = proof_points + 64;
+  uint8_t* S = proof_points + 128;
+  uint8_t* T = proof_points + 192;  // 7 points
+  u256 *aL = f.v[0], *aR = f.v[1], *aO = f.v[2], *sL = f.v[3], *sR = f.v[4], *zwL = f.v[5], *zwR = f.v[6], *zwO = f.v[7];
+  u256 *l1 = f.v[8], *r0 = f.v[9], *r1 = f.v[10], *r3 = f.v[11];
+  u256* hscale = f.v[5];  // after computePolynomials the zs . W vectors are dead
+  const uint32_t nterms = 2 * n2 + 1, nblk = (nterms + 255) / 256;
+  const size_t tb_bytes = ((size_t)nterms * 4 + 255) & ~(size_t)255;
+  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+    ctx->err = "ac_prove_dev: prover workspace too small";
+    return BP_ERR_STATE;
+  }
+  // padAssignment (Internal.hs:91-97): zero-filled to n2; sL, sR already have n2 entries (chooseBlindingVectors n, :32)
+  const size_t vec = (size_t)n2 * 32;
+  BP_TRY(hipMemsetAsync(f.raw, 0, 3 * vec, st));
+  if (n) {
+    BP_TRY(hipMemcpyAsync(f.raw, a_l, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(f.raw + vec, a_r, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(f.raw + 2 * vec, a_o, (size_t)n * 32, hipMemcpyHostToDevice, st));
+  }
+  BP_TRY(hipMemcpyAsync(f.raw + 3 * vec, s_l, vec, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(f.raw + 4 * vec, s_r, vec, hipMemcpyHostToDevice, st));
+  u256* vin[5] = {aL, aR, aO, sL, sR};
+  for (int i = 0; i < 5; i++)
+    if ((rc = frv_from_bytes(ctx, f.raw + (size_t)i * vec, n2, vin[i])) != BP_OK) return rc;
+  // commitBitVector (Internal.hs:102-107): aiCommit, aoCommit (vR = []), sCommit   (Prover.hs:29-33)
+  uint32_t* d_tb = (uint32_t*)w.pts;
+  xyzz* d_part = (xyzz*)(w.pts + tb_bytes);
+  uint8_t* d_out = w.small + 64;
+  std::vector<uint32_t> tb(nterms);
+  for (uint32_t i = 0; i < n2; i++) {
+    tb[i] = fb_base_g(i);
+    tb[n2 + i] = fb_base_h(ng, i);
+  }
+  tb[2 * (size_t)n2] = fb_base_H(ng);
+  BP_TRY(hipMemcpyAsync(d_tb, tb.data(), (size_t)nterms * 4, hipMemcpyHostToDevice, st));
+  if ((rc = frv_ac_commit_scalars(ctx, n2, aL, aR, aO, sL, sR, bytes_as_u256(blind3), bytes_as_u256(blind3 + 32),
+                                  bytes_as_u256(blind3 + 64), w.sc)) != BP_OK)
+    return rc;
+  if ((rc = fb_msm_launch(ctx, 3, nterms, w.sc, d_tb, d_part, nullptr, d_out)) != BP_OK) return rc;
+  BP_TRY(hipMemcpyAsync(AI, d_out, 192, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  const Fr4 aiB = fr_from_bytes(blind3), aoB = fr_from_bytes(blind3 + 32), sB = fr_from_bytes(blind3 + 64);
+
+  uint8_t yb[32], zb[32], xb[32];
+  challenge_y_z(style, AI, AO, S, yb, zb);
+  const Fr4 y = fr_from_bytes(yb), z = fr_from_bytes(zb), yinv = fr_inv(y);
+  // zs = tail (powerVector z (q + 1)); zwL, zwR, zwO = zs `vectorMatrixProduct` W   (Prover.hs:37-42)
+  std::vector<Fr4> zp = power_vector(z, q + 1);
+  std::vector<Fr4> zs(zp.begin() + 1, zp.end());
+  {
+    const size_t zs_bytes = (((size_t)q * 32) + 255) & ~(size_t)255, w_bytes = (size_t)q * n * 32;
+    if (ctx->io.reserve(zs_bytes + w_bytes + 256) != 0) {
+      ctx->err = "staging allocation failed";
+      return BP_ERR_NOMEM;
+    }
+    u256* d_zs = (u256*)ctx->io.p;
+    uint8_t* d_W = (uint8_t*)ctx->io.p + zs_bytes;
+    if (q) BP_TRY(hipMemcpyAsync(d_zs, zs.data(), (size_t)q * 32, hipMemcpyHostToDevice, st));  // Fr4 == u256 layout
+    const uint8_t* Ws[3] = {wL, wR, wO};
+    u256* outs[3] = {zwL, zwR, zwO};
+    for (int i = 0; i < 3; i++) {
+      if (w_bytes) BP_TRY(hipMemcpyAsync(d_W, Ws[i], w_bytes, hipMemcpyHostToDevice, st));
+      if ((rc = frv_ac_vec_mat(ctx, d_zs, d_W, q, n, n2, outs[i])) != BP_OK) return rc;
+    }
+  }
+  // computePolynomials (Prover.hs:104-117) and tPoly = multiplyPoly (Internal.hs:130-139)
+  if ((rc = frv_ac_polys(ctx, n2, aL, aR, sR, fr4_as_u256(y), fr4_as_u256(yinv), zwL, zwR, zwO, l1, r0, r1, r3)) != BP_OK)
+    return rc;
+  if ((rc = frv_ac_tpoly(ctx, n2, l1, aO, sL, r0, r1, r3, f.sm + 8)) != BP_OK) return rc;
+  uint8_t tpoly[7][32];
+  BP_TRY(hipMemcpyAsync(tpoly, f.sm + 8, sizeof(tpoly), hipMemcpyDeviceToHost, st));
+  // hs' = hs_i * y^-i (:76) enters the inner-product argument as scalar factors
+  if ((rc = frv_power_vector(ctx, fr4_as_u256(yinv), n2, hscale)) != BP_OK) return rc;
+  BP_TRY(hipStreamSynchronize(st));  // zs, tb and the weight matrices are read: host temporaries may go
+  Fr4 tc[7];
+  for (int i = 0; i < 7; i++) tc[i] = fr_from_bytes(tpoly[i]);
+  // tBlindings = insertAt 2 0 (0 : five randoms); tCommits = zipWith commit tPoly tBlindings   (Prover.hs:57-58)
+  Fr4 tau[7] = {zero, fr_from_bytes(tau5), zero, fr_from_bytes(tau5 + 32), fr_from_bytes(tau5 + 64),
+                fr_from_bytes(tau5 + 96), fr_from_bytes(tau5 + 128)};
+  {
+    std::vector<uint32_t> tbc{fb_base_G(ng), fb_base_H(ng)};
+    std::vector<Fr4> sc7[7];
+    const std::vector<Fr4>* scs[7];
+    uint8_t* outs[7];
+    for (int i = 0; i < 7; i++) {
+      sc7[i] = {tc[i], tau[i]};
+      scs[i] = &sc7[i];
+      outs[i] = T + 64 * i;
+    }
+    if ((rc = fb_msm_host(ctx, w, tbc, 7, scs, outs)) != BP_OK) return rc;
+  }
+  challenge_x(style, T, xb);
+  const Fr4 x = fr_from_bytes(xb), x2 = fr_sqr(x), x3 = fr_mul(x2, x);
+  // ls = evaluatePolynomial n lPoly x, rs likewise (Prover.hs:63-64), on the device; t = ls . rs = tPoly(x) (:65)
+  if ((rc = frv_ac_eval(ctx, n2, l1, aO, sL, r0, r1, r3, fr4_as_u256(x), fr4_as_u256(x2), fr4_as_u256(x3), f.ls, f.rs)) != BP_OK)
+    return rc;
+  Fr4 t = zero, xp = fr_one();
+  for (int i = 0; i < 7; i++) {
+    t = fr_add(t, fr_mul(tc[i], xp));
+    xp = fr_mul(xp, x);
+  }
+  // tBlinding = sum tau_i x^i + x^2 * (zs . (commitBlinders `vectorMatrixProductT` commitmentWeights))   (:67-70)
+  Fr4 zGamma = zero;
+  for (uint32_t r = 0; r < q; r++) {
+    Fr4 row = zero;
+    for (uint32_t j = 0; j < m; j++)
+      row = fr_add(row, fr_mul(fr_from_bytes(commit_blinders + (size_t)j * 32),
+                               fr_from_bytes(wV + ((size_t)r * m + j) * 32)));
+    zGamma = fr_add(zGamma, fr_mul(zs[r], row));
+  }
+  Fr4 tB = fr_mul(x2, zGamma);
+  xp = fr_one();
+  for (int i = 0; i < 7; i++) {
+    tB = fr_add(tB, fr_mul(tau[i], xp));
+    xp = fr_mul(xp, x);
+  }
+  const Fr4 mu = fr_add(fr_add(fr_mul(aiB, x), fr_mul(aoB, x2)), fr_mul(sB, x3));  // (:72)
+  fr_to_bytes(tB, proof_scalars);
+  fr_to_bytes(mu, proof_scalars + 32);
+  fr_to_bytes(t, proof_scalars + 64);
+  // u = gen * shamirU tBlinding mu t   (:74-75)
+  uint8_t ub[32], D[64], dot0[32];
+  challenge_u(style, proof_scalars, ub);
+  memset(D, 0, 64);
+  std::vector<uint8_t> Lv, Rv;
+  rc = ipp_prove_fixed_dev(ctx, w, n2, hscale, ub, D, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128, dot0);
+  if (rc != BP_OK) return rc;
+  if (memcmp(dot0, proof_scalars + 64, 32) != 0) {  // t = ls . rs must equal tPoly(x)
+    ctx->err = "arithmetic-circuit prover: dot ls rs differs from tPoly(x)";
+    return BP_ERR_STATE;
+  }
+  if (k) {
+    memcpy(proof_points + 640, Lv.data(), (size_t)k * 64);
+    memcpy(proof_points + 640 + (size_t)k * 64, Rv.data(), (size_t)k * 64);
+  }
+  return BP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -189,6 +343,9 @@ int bp_ac_prove(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t* 
   Gens g;
   if ((rc = get_gens(ctx, g)) != BP_OK) return rc;
   const Fr4 zero = fr_zero();
+  if (prover_uses_fixed_base() && prover_vectors_on_device() && n2 > 0 && (size_t)q * n * 32 <= ((size_t)1 << 30))
+    return ac_prove_dev(ctx, w, n, n2, k, q, m, wL, wR, wO, wV, a_l, a_r, a_o, commit_blinders, blind3, s_l, s_r, tau5,
+                        proof_scalars, proof_points);
 
   // padAssignment (Internal.hs:91-97); sL, sR already have the padded length (chooseBlindingVectors n, :32)
   std::vector<Fr4> aL(n2, zero), aR(n2, zero), aO(n2, zero), sL(n2), sR(n2);
@@ -368,7 +525,6 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   BP_REQUIRE(m == 0 || (v_commits && (q == 0 || wV)), "null pointer");
   BP_TRY(hipSetDevice(ctx->device));
   const ShowStyle style = (ShowStyle)ctx->show_style;
-  hipStream_t st = ctx->stream;
   ProverWs w;
   if ((rc = carve_ws(ctx, n2 ? n2 : 1, w, m)) != BP_OK) return rc;
   Gens g;
@@ -494,46 +650,8 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   }
   // IPP.verifyProof n (gs, hs', u) commitmentLR productProof   (InnerProductProof/Verifier.hs:18-38)
   // mkChallenges (:40-53): x_j = shamirX' acc L_j R_j; acc <- x_j^2 L_j + x_j^-2 R_j + acc
-  std::vector<Fr4> chal(k);  // round order; the reference's list is this reversed
-  {
-    uint8_t* d_acc = w.small + 64;
-    uint8_t* d_L = w.small + 128;
-    uint8_t* d_R = w.small + 192;
-    uint8_t* d_new = w.small + 256;
-    BP_TRY(hipMemcpyAsync(d_acc, acc, 64, hipMemcpyHostToDevice, st));
-    // the proof's L_j, R_j are known up front: their shifted forms let eight lanes share each round's chain
-    const bool split = prover_uses_fixed_base() && k > 0 && 2 * k <= 32;
-    if (split) {
-      BP_TRY(hipMemcpyAsync(w.split_pts, Lp, (size_t)2 * k * 64, hipMemcpyHostToDevice, st));
-      if ((rc = ipp_shift_points(ctx, w.split_pts, 2 * k, w.split_sh)) != BP_OK) return rc;
-    }
-    for (uint32_t j = 0; j < k; j++) {
-      const uint8_t* Lj = Lp + (size_t)j * 64;
-      const uint8_t* Rj = Rp + (size_t)j * 64;
-      uint8_t buf[AC_MSG], xjb[32], x2b[32], xi2b[32];
-      Msg mm(buf, style);
-      mm.r();
-      mm.point(Lj);
-      mm.point(Rj);
-      mm.point(acc);
-      mm.finish_fr(xjb);
-      chal[j] = fr_from_bytes(xjb);
-      fr_to_bytes(fr_sqr(chal[j]), x2b);
-      fr_to_bytes(fr_sqr(fr_inv(chal[j])), xi2b);
-      if (split) {
-        if ((rc = ipp_lincomb2_add_split(ctx, w.split_sh + (size_t)j * IPP_SPLIT_S, w.split_sh + (size_t)(k + j) * IPP_SPLIT_S,
-                                         d_acc, x2b, xi2b, w.split_tab, d_new)) != BP_OK)
-          return rc;
-      } else {
-        BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
-        BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
-        if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
-      }
-      BP_TRY(hipMemcpyAsync(acc, d_new, 64, hipMemcpyDeviceToHost, st));
-      BP_TRY(hipMemcpyAsync(d_acc, d_new, 64, hipMemcpyDeviceToDevice, st));
-      BP_TRY(hipStreamSynchronize(st));
-    }
-  }
+  std::vector<Fr4> chal;  // round order; the reference's list is this reversed
+  if ((rc = mk_challenges_dev(ctx, w, style, acc, Lp, Rp, k, chal)) != BP_OK) return rc;
   // mkOtherExponents (:55-73): s_0 = (prod x)^-1, s_{i + 2^j} = s_i * c_j^2 with c_0 the LAST round's challenge
   bool lr_ok;
   {

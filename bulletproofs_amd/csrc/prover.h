@@ -9,6 +9,17 @@
 
 namespace bp {
 
+// Device-resident scalar-field vectors of a proof (frvec.hip): n entries of 32 B each, Montgomery form unless noted.
+struct FrDev {
+  u256 *ls, *rs;     // the inner-product witness, folded in place round by round
+  u256 *cg, *ch;     // fold coefficients of the original generators (plain form)
+  u256* v[12];       // polynomial coefficient vectors of the provers
+  u256* sm;          // 64 small results (dots, polynomial coefficients, the proof's l and r)
+  uint8_t* bits;     // aL of the range prover, one byte per entry
+  uint8_t* raw;      // staging for byte vectors uploaded from the caller: 6 vectors of n x 32 B
+  uint32_t cap;      // n
+};
+
 struct ProverWs {
   uint8_t *G, *H;    // current generator vectors (affine), n points each
   uint8_t *G2, *H2;  // fold outputs (ping-pong)
@@ -20,6 +31,7 @@ struct ProverWs {
   xyzz* split_tab;   // 15 x 64 joint tables of the lane-split round kernel (ipp.hip)
   xyzz* split_sh;    // shifted forms of up to 32 points (L_j, R_j of a proof), 8 each
   uint8_t* split_pts;  // those points, affine
+  FrDev fr;            // scalar-field vectors (frvec.hip)
 };
 
 // carve the workspace for vectors of n points out of ctx->pws (grown on demand); `extra` more gathered terms
@@ -69,10 +81,70 @@ int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<host
 // outs[j] = sum_t (*scalars[j])[t] * base(term_base[t]) (fixedbase.h numbering; scalars in Montgomery form).  Synchronous.
 int fb_msm_host(bp_ctx* ctx, ProverWs& w, const std::vector<uint32_t>& term_base, uint32_t nmsm,
                 const std::vector<host::Fr4>* const* scalars, uint8_t* const* outs);
+// The same with the witness RESIDENT ON THE DEVICE (w.fr.ls, w.fr.rs; d_hscale: n Montgomery-form factors on the device):
+// the dots cL, cR, the scalar folds ls', rs' and the expanded scalars of every round are computed by the kernels of
+// frvec.hip; per round only the challenge goes down (as kernel arguments) and three points come back.  dot0_out
+// (optional) receives <ls, rs> of the initial witness, canonical (the range prover's `t = dot l r` check).
+int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hscale, const uint8_t ub[32],
+                        const uint8_t D[64], host::ShowStyle style, std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs,
+                        uint8_t l_out[32], uint8_t r_out[32], uint8_t* dot0_out);
+// mkChallenges (InnerProductProof/Verifier.hs:40-53): x_j = shamirX' acc L_j R_j; acc <- x_j^2 L_j + x_j^-2 R_j + acc for
+// j < k.  acc: commitmentLR in, the final accumulator out (host bytes); Lp, Rp: k points each (host); chal: the
+// challenges in ROUND order (the reference's list is this reversed).  Hashing on the host, the group work on the GPU
+// (eight lanes per round on shifted forms of L_j, R_j when 2k <= 32).
+int mk_challenges_dev(bp_ctx* ctx, ProverWs& w, host::ShowStyle style, uint8_t acc[64], const uint8_t* Lp,
+                      const uint8_t* Rp, uint32_t k, std::vector<host::Fr4>& chal);
+// BP_PROVER_HOSTVEC=1 keeps the provers' scalar-field vector work on the host (the round-1 path; A/B timing)
+bool prover_vectors_on_device();
 // BP_PROVER_FOLD=1 keeps the provers on ipp_prove_core (device-side generator folds)
 bool prover_uses_fixed_base();
 // fbmsm.hip
 int fb_msm_launch(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms, const uint8_t* d_scalars, const uint32_t* d_term_base,
                   xyzz* d_partial, const uint8_t* d_offset, uint8_t* d_out);
+
+// ---- frvec.hip: launch wrappers, asynchronous on ctx->stream; all pointers are device memory ----------------------
+struct IppVArgs {
+  u256 c2_rev[24];  // squares of the challenges in the REVERSED round order of mkChallenges, Montgomery form
+  u256 s0;          // recip (product challenges), Montgomery form
+  u256 l_plain, r_plain;
+};
+int frv_from_bytes(bp_ctx* ctx, const uint8_t* d_bytes, uint32_t n, u256* d_out);
+int frv_to_bytes(bp_ctx* ctx, const u256* d_in, uint32_t n, uint8_t* d_bytes);
+int frv_power_vector(bp_ctx* ctx, const u256& a, uint32_t n, u256* d_out);
+int frv_hadamard(bp_ctx* ctx, const u256* a, const u256* b, uint32_t n, u256* out);
+int frv_dot(bp_ctx* ctx, const u256* a, const u256* b, uint32_t n, u256* out);
+int frv_rp_commit_scalars(bp_ctx* ctx, uint32_t nm, const uint8_t* bits, const uint8_t* s_l, const uint8_t* s_r,
+                          const u256& alpha, const u256& rho, uint8_t* sc);
+int frv_rp_polys(bp_ctx* ctx, uint32_t n_bits, uint32_t nm, const uint8_t* bits, const u256* s_r, const u256& y,
+                 const u256& z, u256* l0, u256* r0, u256* r1);
+int frv_rp_tpoly(bp_ctx* ctx, uint32_t nm, const u256* l0, const u256* l1, const u256* r0, const u256* r1, u256* out3);
+int frv_rp_eval(bp_ctx* ctx, uint32_t nm, const u256* l0, const u256* l1, const u256* r0, const u256* r1, const u256& x,
+                u256* ls, u256* rs);
+int frv_ipp_init(bp_ctx* ctx, uint32_t n, const u256* hscale, u256* cg, u256* ch);
+int frv_ipp_round(bp_ctx* ctx, uint32_t n, uint32_t nk_prev, bool fold, const u256& x, const u256& xi, const u256& ub,
+                  u256* ls, u256* rs, u256* cg, u256* ch, uint8_t* sc, u256* sm, bool want_scalars);
+int frv_ipp_vscalars(bp_ctx* ctx, uint32_t n, uint32_t lg, const IppVArgs& a, uint8_t* sc);
+int frv_ac_vec_mat(bp_ctx* ctx, const u256* zs, const uint8_t* W, uint32_t q, uint32_t n, uint32_t n2, u256* out);
+int frv_ac_polys(bp_ctx* ctx, uint32_t n2, const u256* a_l, const u256* a_r, const u256* s_r, const u256& y,
+                 const u256& yinv, const u256* zw_l, const u256* zw_r, const u256* zw_o, u256* l1, u256* r0, u256* r1,
+                 u256* r3);
+int frv_ac_tpoly(bp_ctx* ctx, uint32_t n2, const u256* l1, const u256* a_o, const u256* s_l, const u256* r0,
+                 const u256* r1, const u256* r3, u256* out7);
+int frv_ac_eval(bp_ctx* ctx, uint32_t n2, const u256* l1, const u256* a_o, const u256* s_l, const u256* r0,
+                const u256* r1, const u256* r3, const u256& x, const u256& x2, const u256& x3, u256* ls, u256* rs);
+int frv_ac_commit_scalars(bp_ctx* ctx, uint32_t n2, const u256* a_l, const u256* a_r, const u256* a_o, const u256* s_l,
+                          const u256* s_r, const u256& b0, const u256& b1, const u256& b2, uint8_t* sc);
+
+// host Fr4 (4 x u64, Montgomery form with R = 2^256) and the device's u256 (8 x u32) share their bit layout
+static inline u256 fr4_as_u256(const host::Fr4& a) {
+  u256 r;
+  memcpy(r.v, a.v, 32);
+  return r;
+}
+static inline u256 bytes_as_u256(const uint8_t b[32]) {
+  u256 r;
+  memcpy(r.v, b, 32);
+  return r;
+}
 
 }  // namespace bp

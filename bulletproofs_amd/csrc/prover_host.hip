@@ -31,6 +31,15 @@ int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra) {
     w.split_tab = c.take<xyzz>((size_t)15 * 64);
     w.split_sh = c.take<xyzz>((size_t)32 * IPP_SPLIT_S);
     w.split_pts = c.take<uint8_t>((size_t)32 * 64);
+    w.fr.cap = n;
+    w.fr.ls = c.take<u256>(n);
+    w.fr.rs = c.take<u256>(n);
+    w.fr.cg = c.take<u256>(n);
+    w.fr.ch = c.take<u256>(n);
+    for (int i = 0; i < 12; i++) w.fr.v[i] = c.take<u256>(n);
+    w.fr.sm = c.take<u256>(64);
+    w.fr.bits = c.take<uint8_t>(n);
+    w.fr.raw = c.take<uint8_t>((size_t)6 * n * 32);
     return c.off;
   };
   size_t need = carve(nullptr);
@@ -419,6 +428,284 @@ int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<Fr4>
   return BP_OK;
 }
 
+int mk_challenges_dev(bp_ctx* ctx, ProverWs& w, ShowStyle style, uint8_t acc[64], const uint8_t* Lp, const uint8_t* Rp,
+                      uint32_t k, std::vector<Fr4>& chal) {
+  hipStream_t st = ctx->stream;
+  int rc;
+  chal.assign(k, fr_zero());
+  if (k == 0) return BP_OK;
+  uint8_t* d_acc = w.small + 64;
+  uint8_t* d_L = w.small + 128;
+  uint8_t* d_R = w.small + 192;
+  uint8_t* d_new = w.small + 256;
+  BP_TRY(hipMemcpyAsync(d_acc, acc, 64, hipMemcpyHostToDevice, st));
+  // the proof's L_j, R_j are known up front: their shifted forms let eight lanes share each round's chain
+  const bool split = prover_uses_fixed_base() && 2 * k <= 32;
+  if (split) {
+    BP_TRY(hipMemcpyAsync(w.split_pts, Lp, (size_t)k * 64, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(w.split_pts + (size_t)k * 64, Rp, (size_t)k * 64, hipMemcpyHostToDevice, st));
+    if ((rc = ipp_shift_points(ctx, w.split_pts, 2 * k, w.split_sh)) != BP_OK) return rc;
+  }
+  for (uint32_t j = 0; j < k; j++) {
+    const uint8_t* Lj = Lp + (size_t)j * 64;
+    const uint8_t* Rj = Rp + (size_t)j * 64;
+    uint8_t buf[MSG_SCRATCH], xjb[32], x2b[32], xi2b[32];
+    Msg mm(buf, style);
+    mm.r();
+    mm.point(Lj);
+    mm.point(Rj);
+    mm.point(acc);
+    mm.finish_fr(xjb);
+    chal[j] = fr_from_bytes(xjb);
+    fr_to_bytes(fr_sqr(chal[j]), x2b);
+    fr_to_bytes(fr_sqr(fr_inv(chal[j])), xi2b);
+    if (split) {
+      if ((rc = ipp_lincomb2_add_split(ctx, w.split_sh + (size_t)j * IPP_SPLIT_S, w.split_sh + (size_t)(k + j) * IPP_SPLIT_S,
+                                       d_acc, x2b, xi2b, w.split_tab, d_new)) != BP_OK)
+        return rc;
+    } else {
+      BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
+      BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
+      if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
+    }
+    BP_TRY(hipMemcpyAsync(acc, d_new, 64, hipMemcpyDeviceToHost, st));
+    BP_TRY(hipMemcpyAsync(d_acc, d_new, 64, hipMemcpyDeviceToDevice, st));
+    BP_TRY(hipStreamSynchronize(st));
+  }
+  return BP_OK;
+}
+
+bool prover_vectors_on_device() {
+  static const bool host = getenv("BP_PROVER_HOSTVEC") && atoi(getenv("BP_PROVER_HOSTVEC")) != 0;
+  return !host;
+}
+
+int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hscale, const uint8_t ub[32],
+                        const uint8_t D[64], ShowStyle style, std::vector<uint8_t>& Ls, std::vector<uint8_t>& Rs,
+                        uint8_t l_out[32], uint8_t r_out[32], uint8_t* dot0_out) {
+  hipStream_t st = ctx->stream;
+  if (n == 0) {  // ([], []) -> InnerProductProof [] [] 0 0   (Prover.hs:42)
+    memset(l_out, 0, 32);
+    memset(r_out, 0, 32);
+    if (dot0_out) memset(dot0_out, 0, 32);
+    return BP_OK;
+  }
+  const uint32_t ng = ctx->n_gens;
+  if (n > ng || (n & (n - 1)) != 0 || n > w.fr.cap) {
+    ctx->err = "ipp_prove_fixed_dev: n must be a power of two within the context's generators and the workspace";
+    return BP_ERR_ARG;
+  }
+  const uint32_t nterms = 2 * n + 1, nblk = (nterms + 255) / 256;
+  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 ||
+      (((size_t)nterms * 4 + 255) & ~(size_t)255) + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+    ctx->err = "ipp_prove_fixed_dev: prover workspace too small";
+    return BP_ERR_STATE;
+  }
+  FrDev& f = w.fr;
+  uint8_t* d_sc = w.sc;
+  uint32_t* d_tb = (uint32_t*)w.pts;
+  xyzz* d_part = (xyzz*)(w.pts + (((size_t)nterms * 4 + 255) & ~(size_t)255));
+  uint8_t* d_off = w.small;
+  uint8_t* d_out = w.small + 64;
+  int rc;
+  const u256 ubm = fr4_as_u256(fr_from_bytes(ub));
+  const u256 zero = u256_zero();
+  struct {
+    uint8_t pts[3][64];
+    uint8_t sm[3][32];
+  } res;
+  auto fetch = [&](bool points) -> int {
+    if (points) BP_TRY(hipMemcpyAsync(res.pts, d_out, sizeof(res.pts), hipMemcpyDeviceToHost, st));
+    BP_TRY(hipMemcpyAsync(res.sm, f.sm, sizeof(res.sm), hipMemcpyDeviceToHost, st));
+    BP_TRY(hipStreamSynchronize(st));
+    return BP_OK;
+  };
+  if (n == 1) {  // ([l], [r]): no round, commitmentLR is never hashed (Prover.hs:43)
+    if ((rc = frv_ipp_round(ctx, n, 1, false, zero, zero, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, f.sm, false)) != BP_OK) return rc;
+    if ((rc = fetch(false)) != BP_OK) return rc;
+    if (dot0_out) memcpy(dot0_out, res.sm[0], 32);
+    memcpy(l_out, res.sm[1], 32);
+    memcpy(r_out, res.sm[2], 32);
+    return BP_OK;
+  }
+  {
+    std::vector<uint32_t> tb(nterms);
+    for (uint32_t i = 0; i < n; i++) {
+      tb[i] = fb_base_g(i);
+      tb[n + i] = fb_base_h(ng, i);
+    }
+    tb[2 * n] = fb_base_G(ng);
+    BP_TRY(hipMemcpyAsync(d_tb, tb.data(), (size_t)nterms * 4, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(d_off, D, 64, hipMemcpyHostToDevice, st));
+    if ((rc = frv_ipp_init(ctx, n, d_hscale, f.cg, f.ch)) != BP_OK) return rc;
+    BP_TRY(hipStreamSynchronize(st));  // tb lives on this frame
+  }
+  // commitment of (ls, rs) under the folded base and the next lCommit / rCommit: three sums over the 2n + 1 generators
+  auto launch = [&](uint32_t nk_prev, bool fold, const u256& x, const u256& xi) -> int {
+    int r2 = frv_ipp_round(ctx, n, nk_prev, fold, x, xi, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, f.sm, true);
+    if (r2 != BP_OK) return r2;
+    if ((r2 = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, d_out)) != BP_OK) return r2;
+    return fetch(true);
+  };
+  uint32_t nk = n;
+  if ((rc = launch(nk, false, zero, zero)) != BP_OK) return rc;
+  if (dot0_out) memcpy(dot0_out, res.sm[0], 32);
+  while (nk > 1) {
+    const uint8_t *P = res.pts[0], *L = res.pts[1], *R = res.pts[2];
+    Ls.insert(Ls.end(), L, L + 64);
+    Rs.insert(Rs.end(), R, R + 64);
+    // x = shamirX' commitmentLR lCommit rCommit   (:75)
+    uint8_t buf[MSG_SCRATCH], xb[32];
+    Msg mm(buf, style);
+    mm.r();
+    mm.point(L);
+    mm.point(R);
+    mm.point(P);
+    mm.finish_fr(xb);
+    const Fr4 x = fr_from_bytes(xb), xi = fr_inv(x);
+    // ls', rs' (:84-85), the fold coefficients (:81-82) and the next round's scalars: on the device
+    if (nk > 2) {
+      if ((rc = launch(nk, true, fr4_as_u256(x), fr4_as_u256(xi))) != BP_OK) return rc;
+    } else {  // last fold: only l, r are left
+      if ((rc = frv_ipp_round(ctx, n, nk, true, fr4_as_u256(x), fr4_as_u256(xi), ubm, f.ls, f.rs, f.cg, f.ch, d_sc, f.sm,
+                              false)) != BP_OK)
+        return rc;
+      if ((rc = fetch(false)) != BP_OK) return rc;
+    }
+    nk /= 2;
+  }
+  memcpy(l_out, res.sm[1], 32);
+  memcpy(r_out, res.sm[2], 32);
+  return BP_OK;
+}
+
+
+// generateProofUnsafe (MultiRangeProof/Prover.hs:47-123) with every O(nm) scalar-field vector on the device:
+// commitBitVectors' scalars, computeLRPolys, computeTPoly, ls / rs, powerVector (recip y) and the whole inner-product
+// recursion (frvec.hip).  The host keeps the transcript, the scalars tBlinding / mu / t and the control flow.
+// bits: aL, one byte per entry (nm of them: every value in range).
+static int rangeproof_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t m, uint32_t m2, uint32_t nm, uint32_t k,
+                                const std::vector<uint8_t>& bits, const uint8_t* blindings, const uint8_t* sL,
+                                const uint8_t* sR, const uint8_t* alpha, const uint8_t* rho, const uint8_t* tau1,
+                                const uint8_t* tau2, uint8_t* proof_scalars, uint8_t* proof_points) {
+  const ShowStyle style = (ShowStyle)ctx->show_style;
+  hipStream_t st = ctx->stream;
+  const uint32_t ng = ctx->n_gens;
+  FrDev& f = w.fr;
+  int rc;
+  uint8_t* A = proof_points;
+  uint8_t* S = proof_points + 64;
+  uint8_t* T1 = proof_points + 128;
+  uint8_t* T2 = proof_points + 192;
+  u256 *l0 = f.v[0], *r0 = f.v[1], *r1 = f.v[2], *l1 = f.v[3], *sRm = f.v[4], *hscale = f.v[5];
+  uint8_t* raw_sL = f.raw;
+  uint8_t* raw_sR = f.raw + (size_t)nm * 32;
+  const uint32_t nterms = 2 * nm + 1, nblk = (nterms + 255) / 256;
+  const size_t tb_bytes = ((size_t)nterms * 4 + 255) & ~(size_t)255;
+  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+    ctx->err = "rangeproof_prove_dev: prover workspace too small";
+    return BP_ERR_STATE;
+  }
+  uint32_t* d_tb = (uint32_t*)w.pts;
+  xyzz* d_part = (xyzz*)(w.pts + tb_bytes);
+  uint8_t* d_out = w.small + 64;
+  // commitBitVectors: A = aBlinding*h + <aL, gs> + <aR, hs>, S likewise   (RangeProof/Internal.hs:136-147)
+  std::vector<uint32_t> tb(nterms);
+  for (uint32_t i = 0; i < nm; i++) {
+    tb[i] = fb_base_g(i);
+    tb[nm + i] = fb_base_h(ng, i);
+  }
+  tb[2 * (size_t)nm] = fb_base_H(ng);
+  BP_TRY(hipMemcpyAsync(d_tb, tb.data(), (size_t)nterms * 4, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(f.bits, bits.data(), nm, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(raw_sL, sL, (size_t)nm * 32, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(raw_sR, sR, (size_t)nm * 32, hipMemcpyHostToDevice, st));
+  if ((rc = frv_rp_commit_scalars(ctx, nm, f.bits, raw_sL, raw_sR, bytes_as_u256(alpha), bytes_as_u256(rho), w.sc)) != BP_OK)
+    return rc;
+  if ((rc = fb_msm_launch(ctx, 2, nterms, w.sc, d_tb, d_part, nullptr, d_out)) != BP_OK) return rc;
+  BP_TRY(hipMemcpyAsync(A, d_out, 128, hipMemcpyDeviceToHost, st));
+  if ((rc = frv_from_bytes(ctx, raw_sL, nm, l1)) != BP_OK) return rc;  // l1 = sL (Prover.hs:143)
+  if ((rc = frv_from_bytes(ctx, raw_sR, nm, sRm)) != BP_OK) return rc;
+  BP_TRY(hipStreamSynchronize(st));  // A, S are in; tb, bits live on this frame
+  // y, z   (Prover.hs:75-76)
+  uint8_t buf[MSG_SCRATCH], keep[MSG_SCRATCH], yb[32], zb[32], xb[32];
+  Msg my(buf, style);
+  my.r();
+  my.point(A);
+  my.point(S);
+  size_t pre = my.len;
+  memcpy(keep, buf, pre);
+  my.finish_fr(yb);
+  Msg mz(buf, style);
+  mz.raw(keep, pre);
+  mz.fr(yb);
+  mz.finish_fr(zb);
+  const Fr4 y = fr_from_bytes(yb), z = fr_from_bytes(zb);
+  // computeLRPolys / computeTPoly   (Prover.hs:133-169)
+  if ((rc = frv_rp_polys(ctx, n, nm, f.bits, sRm, fr4_as_u256(y), fr4_as_u256(z), l0, r0, r1)) != BP_OK) return rc;
+  if ((rc = frv_rp_tpoly(ctx, nm, l0, l1, r0, r1, f.sm + 8)) != BP_OK) return rc;
+  uint8_t tpoly[3][32];
+  BP_TRY(hipMemcpyAsync(tpoly, f.sm + 8, sizeof(tpoly), hipMemcpyDeviceToHost, st));
+  // hs' = hs_i * recip(y^i) (Prover.hs:107) enters the inner-product argument as scalar factors
+  if ((rc = frv_power_vector(ctx, fr4_as_u256(fr_inv(y)), nm, hscale)) != BP_OK) return rc;
+  BP_TRY(hipStreamSynchronize(st));
+  const Fr4 t0 = fr_from_bytes(tpoly[0]), t1 = fr_from_bytes(tpoly[1]), t2 = fr_from_bytes(tpoly[2]);
+  // t1Commit = commit t1 t1Blinding, t2Commit likewise   (Prover.hs:84-85; Utils.hs:84-85)
+  {
+    std::vector<uint32_t> tbc{fb_base_G(ng), fb_base_H(ng)};
+    std::vector<Fr4> s1{t1, fr_from_bytes(tau1)}, s2{t2, fr_from_bytes(tau2)};
+    const std::vector<Fr4>* scs[2] = {&s1, &s2};
+    uint8_t* outs[2] = {T1, T2};
+    if ((rc = fb_msm_host(ctx, w, tbc, 2, scs, outs)) != BP_OK) return rc;
+  }
+  // x   (Prover.hs:88)
+  Msg mx(buf, style);
+  mx.raw(keep, pre);
+  mx.point(T1);
+  mx.point(T2);
+  mx.fr(yb);
+  mx.fr(zb);
+  mx.finish_fr(xb);
+  const Fr4 x = fr_from_bytes(xb), x2 = fr_sqr(x);
+  // ls, rs on the device; t, tBlinding, mu   (Prover.hs:90-103)
+  if ((rc = frv_rp_eval(ctx, nm, l0, l1, r0, r1, fr4_as_u256(x), f.ls, f.rs)) != BP_OK) return rc;
+  const Fr4 t = fr_add(fr_add(t0, fr_mul(t1, x)), fr_mul(t2, x2));
+  Fr4 zp = fr_mul(z, z), tbl = fr_add(fr_mul(fr_from_bytes(tau2), x2), fr_mul(fr_from_bytes(tau1), x));
+  for (uint32_t j = 0; j < m; j++) {
+    tbl = fr_add(tbl, fr_mul(zp, fr_from_bytes(blindings + (size_t)j * 32)));
+    zp = fr_mul(zp, z);
+  }
+  (void)m2;
+  const Fr4 mu = fr_add(fr_from_bytes(alpha), fr_mul(fr_from_bytes(rho), x));
+  fr_to_bytes(tbl, proof_scalars);
+  fr_to_bytes(mu, proof_scalars + 32);
+  fr_to_bytes(t, proof_scalars + 64);
+  // u = gen * shamirU tBlinding mu t   (Prover.hs:105-106): a scalar factor on gen
+  uint8_t ub[32];
+  Msg mu_(buf, style);
+  mu_.r();
+  mu_.fr(proof_scalars);
+  mu_.fr(proof_scalars + 32);
+  mu_.fr(proof_scalars + 64);
+  mu_.finish_fr(ub);
+  // productProof = IPP.generateProof (gs, hs', u) commitmentLR (ls, rs)   (Prover.hs:108-112); commitmentLR is the
+  // commitment of the prover's own ls, rs, t (offset O)
+  uint8_t D[64], dot0[32];
+  memset(D, 0, 64);
+  std::vector<uint8_t> Lv, Rv;
+  rc = ipp_prove_fixed_dev(ctx, w, nm, hscale, ub, D, style, Lv, Rv, proof_scalars + 96, proof_scalars + 128, dot0);
+  if (rc != BP_OK) return rc;
+  if (memcmp(dot0, proof_scalars + 64, 32) != 0) {  // the reference panics here (Prover.hs:94-95)
+    ctx->err = "Error on: t = dot l r";
+    return BP_ERR_STATE;
+  }
+  if (k) {
+    memcpy(proof_points + 256, Lv.data(), (size_t)k * 64);
+    memcpy(proof_points + 256 + (size_t)k * 64, Rv.data(), (size_t)k * 64);
+  }
+  return BP_OK;
+}
+
 }  // namespace bp
 
 extern "C" {
@@ -454,6 +741,103 @@ int bp_ipp_prove(bp_ctx* ctx, uint32_t n, const uint8_t* Gs, const uint8_t* Hs, 
     memcpy(L_out, Lv.data(), Lv.size());
     memcpy(R_out, Rv.data(), Rv.size());
   }
+  return BP_OK;
+}
+
+// IPP.verifyProof n base commitmentLR proof (InnerProductProof/Verifier.hs:18-38) on a caller-supplied base.
+//   n       the reference's `n` (an Integer there: the vector length the proof is for)
+//   Gs, Hs  bGs (n_gs points), bHs (n_hs points); u = bH; P = commitmentLR
+//   L, R    k points each = zip lCommits rCommits (:53); l, r: the proof's scalars
+// mkChallenges walks the k rounds (hash on the host, x^2 L + x^-2 R + acc on the GPU); mkOtherExponents and the
+// scalars of cProof = l <s, Gs> + r <reverse s, Hs> + (l r) bH are a kernel when n is a power of two that the bases
+// cover (frvec.hip), else the reference's Map walk on the host (first insert wins; `sumExps` truncates to the shorter
+// list, Utils.hs:79); one variable-base MSM of 2n + 1 terms; verdict = (acc == cProof) on affine bytes.
+// Where the reference would fail with an index error (fewer rounds than logBase2 n), this returns BP_ERR_ARG.
+int bp_ipp_verify(bp_ctx* ctx, uint64_t n64, const uint8_t* Gs, uint32_t n_gs, const uint8_t* Hs, uint32_t n_hs,
+                  const uint8_t* u, const uint8_t* P, const uint8_t* L, const uint8_t* R, uint32_t k, const uint8_t* l,
+                  const uint8_t* r, uint8_t* verdict) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(u && P && l && r && verdict, "null pointer");
+  BP_REQUIRE(n64 <= (1u << 20) && n_gs <= (1u << 20) && n_hs <= (1u << 20), "n too large (limit 2^20)");
+  BP_REQUIRE(k <= 64 && (k == 0 || (L && R)), "bad round count or null pointer");
+  BP_REQUIRE((n_gs == 0 || Gs) && (n_hs == 0 || Hs), "null pointer");
+  const uint32_t n = (uint32_t)n64;
+  // logBase2 n = floor (logBase 2.0 n) (Utils.hs:93-94); for n = 0 the reference's range [0 .. logBase2 n - 1] is empty
+  uint32_t lg = 0;
+  while (n >= 2 && (2u << lg) <= n) lg++;
+  if (n >= 2 && lg > k) {
+    ctx->err = "bp_ipp_verify: fewer L/R rounds than logBase2 n (the reference fails with an index error here)";
+    return BP_ERR_ARG;
+  }
+  BP_TRY(hipSetDevice(ctx->device));
+  const ShowStyle style = (ShowStyle)ctx->show_style;
+  hipStream_t st = ctx->stream;
+  const uint32_t cap = n > n_gs ? (n > n_hs ? n : n_hs) : (n_gs > n_hs ? n_gs : n_hs);
+  ProverWs w;
+  int rc = carve_ws(ctx, cap ? cap : 1, w);
+  if (rc != BP_OK) return rc;
+  // mkChallenges (:40-53)
+  uint8_t acc[64];
+  memcpy(acc, P, 64);
+  std::vector<Fr4> chal;
+  if ((rc = mk_challenges_dev(ctx, w, style, acc, L, R, k, chal)) != BP_OK) return rc;
+  Fr4 prod = fr_one();
+  for (uint32_t j = 0; j < k; j++) prod = fr_mul(prod, chal[j]);
+  const Fr4 s0 = fr_inv(prod);  // recip (product challenges); recip 0 = 0 cannot arise from a hash in [0, r) but stays total
+  const Fr4 lm = fr_from_bytes(l), rm = fr_from_bytes(r);
+  uint8_t lc[32], rcn[32];
+  fr_to_bytes(lm, lc);
+  fr_to_bytes(rm, rcn);
+  size_t a = 0, b = 0;  // terms taken from Gs, Hs
+  const bool pow2 = n >= 1 && (n & (n - 1)) == 0;
+  if (pow2 && n_gs >= n && n_hs >= n && lg <= 24) {
+    a = b = n;
+    IppVArgs va;
+    memset((void*)&va, 0, sizeof(va));
+    for (uint32_t j = 0; j < lg; j++) va.c2_rev[j] = fr4_as_u256(fr_sqr(chal[k - 1 - j]));  // challenges !! j
+    va.s0 = fr4_as_u256(s0);
+    va.l_plain = bytes_as_u256(lc);
+    va.r_plain = bytes_as_u256(rcn);
+    if ((rc = frv_ipp_vscalars(ctx, n, lg, va, w.sc)) != BP_OK) return rc;
+  } else {
+    // mkOtherExponents as written (:55-73): a Map from index to exponent, first insert wins
+    std::vector<Fr4> accm(n ? n : 1, fr_zero());
+    std::vector<uint8_t> present(n ? n : 1, 0);
+    accm[0] = s0;
+    present[0] = 1;
+    for (uint32_t i = 0; i < n / 2; i++)
+      for (uint32_t j = 0; j < lg; j++) {
+        const uint64_t i1 = ((uint64_t)1 << j) + i;
+        if (i1 >= n || present[i1]) continue;
+        if (!present[i]) {
+          ctx->err = "bp_ipp_verify: mkOtherExponents reads a missing key (the reference fails here)";
+          return BP_ERR_ARG;
+        }
+        accm[i1] = fr_mul(accm[i], fr_sqr(chal[k - 1 - j]));
+        present[i1] = 1;
+      }
+    std::vector<Fr4> other;  // Map.elems: ascending keys
+    for (uint32_t i = 0; i < (n ? n : 1); i++)
+      if (present[i]) other.push_back(accm[i]);
+    const size_t len = other.size();
+    a = len < n_gs ? len : n_gs;  // sumExps otherExponents bGs truncates to the shorter list (Utils.hs:79)
+    b = len < n_hs ? len : n_hs;  // sumExps (reverse otherExponents) bHs
+    std::vector<uint8_t> sc((a + b + 1) * 32);
+    for (size_t t = 0; t < a; t++) fr_to_bytes(fr_mul(lm, other[t]), &sc[t * 32]);
+    for (size_t t = 0; t < b; t++) fr_to_bytes(fr_mul(rm, other[len - 1 - t]), &sc[(a + t) * 32]);
+    fr_to_bytes(fr_mul(lm, rm), &sc[(a + b) * 32]);
+    BP_TRY(hipMemcpyAsync(w.sc, sc.data(), sc.size(), hipMemcpyHostToDevice, st));
+    BP_TRY(hipStreamSynchronize(st));  // `sc` is a host temporary
+  }
+  if (a) BP_TRY(hipMemcpyAsync(w.pts, Gs, a * 64, hipMemcpyHostToDevice, st));
+  if (b) BP_TRY(hipMemcpyAsync(w.pts + a * 64, Hs, b * 64, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(w.pts + (a + b) * 64, u, 64, hipMemcpyHostToDevice, st));
+  uint8_t* d_out = w.small + 15 * 64;
+  if ((rc = msm_run(ctx, w.sc, w.pts, a + b + 1, 0, d_out, nullptr)) != BP_OK) return rc;
+  uint8_t cproof[64];
+  BP_TRY(hipMemcpyAsync(cproof, d_out, 64, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  *verdict = memcmp(cproof, acc, 64) == 0 ? 1 : 0;  // c == cProof   (:27)
   return BP_OK;
 }
 
@@ -547,6 +931,12 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
   ProverWs w;
   int rc = carve_ws(ctx, n_digits, w);
   if (rc != BP_OK) return rc;
+  if (prover_uses_fixed_base() && prover_vectors_on_device() && n_digits == nm) {
+    std::vector<uint8_t> bits(nm);
+    for (uint32_t i = 0; i < nm; i++) bits[i] = fr_is_zero(aL[i]) ? 0 : 1;
+    return rangeproof_prove_dev(ctx, w, n, m, m2, nm, k, bits, blindings, sL, sR, alpha, rho, tau1, tau2, proof_scalars,
+                                proof_points);
+  }
   const uint8_t* d_gs = ctx->d_bases;
   const uint8_t* d_hs = ctx->d_bases + (size_t)ng * 64;
   const uint8_t* d_gen = ctx->d_bases + (size_t)2 * ng * 64;
@@ -746,6 +1136,126 @@ int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t*
     memcpy(proof_points + 256, Lv.data(), (size_t)k * 64);
     memcpy(proof_points + 256 + (size_t)k * 64, Rv.data(), (size_t)k * 64);
   }
+  return BP_OK;
+}
+
+// ---- self-test hooks of the scalar-field vector kernels (frvec.hip), used by the parity tests ----------------------
+// op 0: out[0..n) = powerVector a n (Utils.hs:50-52; a: one scalar)   1: out[0..n) = hadamard a b (n each, :55-58)
+// op 2: out[0] = dot a b (:60-61).  Canonical 32-byte scalars in host memory.
+int bp_fr_vector_op(bp_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint32_t n, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(op >= 0 && op <= 2 && a && out && (op == 0 || b), "bad selector or null pointer");
+  BP_REQUIRE(n <= (1u << 20), "n too large");
+  BP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ProverWs w;
+  int rc = carve_ws(ctx, n ? n : 1, w);
+  if (rc != BP_OK) return rc;
+  FrDev& f = w.fr;
+  const size_t vec = (size_t)n * 32;
+  uint32_t n_out = n;
+  if (op == 0) {
+    if ((rc = frv_power_vector(ctx, fr4_as_u256(fr_from_bytes(a)), n, f.v[2])) != BP_OK) return rc;
+  } else {
+    if (n) {
+      BP_TRY(hipMemcpyAsync(f.raw, a, vec, hipMemcpyHostToDevice, st));
+      BP_TRY(hipMemcpyAsync(f.raw + vec, b, vec, hipMemcpyHostToDevice, st));
+    }
+    if ((rc = frv_from_bytes(ctx, f.raw, n, f.v[0])) != BP_OK) return rc;
+    if ((rc = frv_from_bytes(ctx, f.raw + vec, n, f.v[1])) != BP_OK) return rc;
+    if (op == 1) {
+      if ((rc = frv_hadamard(ctx, f.v[0], f.v[1], n, f.v[2])) != BP_OK) return rc;
+    } else {
+      if ((rc = frv_dot(ctx, f.v[0], f.v[1], n, f.v[2])) != BP_OK) return rc;
+      n_out = 1;
+    }
+  }
+  if ((rc = frv_to_bytes(ctx, f.v[2], n_out, f.raw + 2 * vec)) != BP_OK) return rc;
+  if (n_out) BP_TRY(hipMemcpyAsync(out, f.raw + 2 * vec, (size_t)n_out * 32, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  return BP_OK;
+}
+
+// computeLRPolys / computeTPoly / ls, rs (MultiRangeProof/Prover.hs:90-91,133-169) as the range prover's kernels
+// evaluate them.  bits: aL, nm = n_bits * m bytes (0/1); s_l, s_r: nm scalars; y, z, x: one scalar each.
+// out: (5 nm + 3) scalars: l0 | r0 | r1 | ls | rs | t0 t1 t2.
+int bp_rp_polys_selftest(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t* bits, const uint8_t* s_l,
+                         const uint8_t* s_r, const uint8_t* y, const uint8_t* z, const uint8_t* x, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(bits && s_l && s_r && y && z && x && out, "null pointer");
+  BP_REQUIRE(n_bits >= 1 && m >= 1 && (uint64_t)n_bits * m <= 8192, "n_bits * m out of range");
+  const uint32_t nm = n_bits * m;
+  BP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ProverWs w;
+  int rc = carve_ws(ctx, nm, w);
+  if (rc != BP_OK) return rc;
+  FrDev& f = w.fr;
+  const size_t vec = (size_t)nm * 32;
+  BP_TRY(hipMemcpyAsync(f.bits, bits, nm, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(f.raw, s_l, vec, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(f.raw + vec, s_r, vec, hipMemcpyHostToDevice, st));
+  u256 *l0 = f.v[0], *r0 = f.v[1], *r1 = f.v[2], *l1 = f.v[3], *sRm = f.v[4];
+  if ((rc = frv_from_bytes(ctx, f.raw, nm, l1)) != BP_OK) return rc;
+  if ((rc = frv_from_bytes(ctx, f.raw + vec, nm, sRm)) != BP_OK) return rc;
+  if ((rc = frv_rp_polys(ctx, n_bits, nm, f.bits, sRm, fr4_as_u256(fr_from_bytes(y)), fr4_as_u256(fr_from_bytes(z)), l0, r0,
+                         r1)) != BP_OK)
+    return rc;
+  if ((rc = frv_rp_tpoly(ctx, nm, l0, l1, r0, r1, f.sm + 8)) != BP_OK) return rc;
+  if ((rc = frv_rp_eval(ctx, nm, l0, l1, r0, r1, fr4_as_u256(fr_from_bytes(x)), f.ls, f.rs)) != BP_OK) return rc;
+  const u256* vs[5] = {l0, r0, r1, f.ls, f.rs};
+  for (int i = 0; i < 5; i++) {
+    if ((rc = frv_to_bytes(ctx, vs[i], nm, f.raw + 2 * vec)) != BP_OK) return rc;
+    BP_TRY(hipMemcpyAsync(out + (size_t)i * vec, f.raw + 2 * vec, vec, hipMemcpyDeviceToHost, st));
+  }
+  BP_TRY(hipMemcpyAsync(out + 5 * vec, f.sm + 8, 96, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
+  return BP_OK;
+}
+
+// `rounds` recursion steps of generateProof' (InnerProductProof/Prover.hs:52-92) on the witness alone, as the
+// provers' kernels run them: ls, rs (n scalars, n a power of two), hscale (n: the factors y^-i on hs), ub (bH = ub * gen),
+// xs: the challenges of the rounds.  out: nk = n >> rounds; ls' (nk) | rs' (nk) | dot, cL, cR of the folded
+// witness (3) | the scalars of the three sums over the 2n + 1 original generators (3 (2n + 1)).
+int bp_ipp_fold_selftest(bp_ctx* ctx, uint32_t n, const uint8_t* ls, const uint8_t* rs, const uint8_t* hscale,
+                         const uint8_t* ub, uint32_t rounds, const uint8_t* xs, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(ls && rs && hscale && ub && out && (rounds == 0 || xs), "null pointer");
+  BP_REQUIRE(n >= 1 && n <= 8192 && (n & (n - 1)) == 0 && (n >> rounds) >= 1, "n must be a power of two >= 2^rounds");
+  BP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ProverWs w;
+  int rc = carve_ws(ctx, n, w);
+  if (rc != BP_OK) return rc;
+  FrDev& f = w.fr;
+  const size_t vec = (size_t)n * 32, nt = (size_t)2 * n + 1;
+  BP_TRY(hipMemcpyAsync(f.raw, ls, vec, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(f.raw + vec, rs, vec, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(f.raw + 2 * vec, hscale, vec, hipMemcpyHostToDevice, st));
+  if ((rc = frv_from_bytes(ctx, f.raw, n, f.ls)) != BP_OK) return rc;
+  if ((rc = frv_from_bytes(ctx, f.raw + vec, n, f.rs)) != BP_OK) return rc;
+  if ((rc = frv_from_bytes(ctx, f.raw + 2 * vec, n, f.v[0])) != BP_OK) return rc;
+  if ((rc = frv_ipp_init(ctx, n, f.v[0], f.cg, f.ch)) != BP_OK) return rc;
+  const u256 ubm = fr4_as_u256(fr_from_bytes(ub)), zero = u256_zero();
+  uint32_t nk = n;
+  if ((rc = frv_ipp_round(ctx, n, nk, false, zero, zero, ubm, f.ls, f.rs, f.cg, f.ch, w.sc, f.sm, true)) != BP_OK) return rc;
+  for (uint32_t r = 0; r < rounds; r++) {
+    const Fr4 x = fr_from_bytes(xs + (size_t)r * 32), xi = fr_inv(x);
+    if ((rc = frv_ipp_round(ctx, n, nk, true, fr4_as_u256(x), fr4_as_u256(xi), ubm, f.ls, f.rs, f.cg, f.ch, w.sc, f.sm,
+                            true)) != BP_OK)
+      return rc;
+    nk /= 2;
+  }
+  const size_t vk = (size_t)nk * 32;
+  if ((rc = frv_to_bytes(ctx, f.ls, nk, f.raw)) != BP_OK) return rc;
+  if ((rc = frv_to_bytes(ctx, f.rs, nk, f.raw + vk)) != BP_OK) return rc;
+  BP_TRY(hipMemcpyAsync(out, f.raw, 2 * vk, hipMemcpyDeviceToHost, st));
+  // dot, cL, cR: recover them from the bH scalars would need ub^-1; sm[0] holds dot, the sums' bH entries hold ub * {dot, cL, cR}
+  BP_TRY(hipMemcpyAsync(out + 2 * vk, f.sm, 32, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipMemcpyAsync(out + 2 * vk + 32, w.sc + (nt + 2 * (size_t)n) * 32, 32, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipMemcpyAsync(out + 2 * vk + 64, w.sc + (2 * nt + 2 * (size_t)n) * 32, 32, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipMemcpyAsync(out + 2 * vk + 96, w.sc, 3 * nt * 32, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));
   return BP_OK;
 }
 

@@ -242,6 +242,15 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts);
 int bp_ipp_prove(bp_ctx* ctx, uint32_t n, const uint8_t* Gs, const uint8_t* Hs, const uint8_t* u, const uint8_t* P,
                  const uint8_t* ls, const uint8_t* rs, uint8_t* L_out, uint8_t* R_out, uint8_t* l_out,
                  uint8_t* r_out);
+/* bp_ipp_verify     InnerProductProof.verifyProof n base commitmentLR proof on an arbitrary base
+ *                   (Bulletproofs/InnerProductProof/Verifier.hs:18-73, exported at InnerProductProof.hs:1-7).
+ *                   n: the reference's Integer argument (<= 2^20); Gs = bGs (n_gs points), Hs = bHs (n_hs points),
+ *                   u = bH, P = commitmentLR; L, R: k points each (zip lCommits rCommits); l, r: 32 bytes each.
+ *                   *verdict = 1/0.  Lists shorter than n truncate the sums exactly as `sumExps` does
+ *                   (Utils.hs:79); fewer rounds than logBase2 n, where the reference's `!!` fails, is BP_ERR_ARG. */
+int bp_ipp_verify(bp_ctx* ctx, uint64_t n, const uint8_t* Gs, uint32_t n_gs, const uint8_t* Hs, uint32_t n_hs,
+                  const uint8_t* u, const uint8_t* P, const uint8_t* L, const uint8_t* R, uint32_t k, const uint8_t* l,
+                  const uint8_t* r, uint8_t* verdict);
 int bp_upper_bound_bits(const uint8_t* upper_bound, size_t len, uint32_t* n_bits);
 int bp_rangeproof_prove(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t* values, const uint8_t* blindings,
                         const uint8_t* sL, const uint8_t* sR, const uint8_t* alpha, const uint8_t* rho,
@@ -304,6 +313,25 @@ int bp_rangeproof_show(const uint8_t* scalars, const uint8_t* points, uint32_t k
  * `Fr`/`Fq` (galois-field, imported at Utils.hs:8; laws in test/Test/Field.hs:39-64).
  */
 int bp_field_op(bp_ctx* ctx, int field, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+
+/* ---- scalar-field vector kernels: self-test hooks (used by the parity tests) ----
+ * The provers keep their witness vectors in HBM and run the reference's vector algebra as kernels; these hooks run the
+ * same kernels on caller data (canonical 32-byte scalars, host pointers).
+ * bp_fr_vector_op      op 0 powerVector a n (Utils.hs:50-52, incl. powerVector 0 n = zeros; a: one scalar, b unused)
+ *                      op 1 hadamard a b (Utils.hs:55-58)   op 2 dot a b (Utils.hs:60-61; one scalar out)
+ * bp_rp_polys_selftest computeLRPolys, computeTPoly and ls = l0 + x l1, rs = r0 + x r1
+ *                      (MultiRangeProof/Prover.hs:90-91,133-169).  bits: aL as n_bits * m bytes of 0/1.
+ *                      out: 5 n m + 3 scalars: l0 | r0 | r1 | ls | rs | t0 t1 t2.
+ * bp_ipp_fold_selftest `rounds` steps of generateProof' on the witness (InnerProductProof/Prover.hs:60-61,84-85) with
+ *                      challenges xs, and the scalars that express lCommit, rCommit and the folded commitment over
+ *                      the ORIGINAL generators (hs' = hscale_i * hs_i, bH = ub * gen).  out: nk = n >> rounds;
+ *                      ls' (nk) | rs' (nk) | dot, ub*cL, ub*cR | 3 x (2n + 1) scalars (gs part, hs part, gen).
+ */
+int bp_fr_vector_op(bp_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint32_t n, uint8_t* out);
+int bp_rp_polys_selftest(bp_ctx* ctx, uint32_t n_bits, uint32_t m, const uint8_t* bits, const uint8_t* s_l,
+                         const uint8_t* s_r, const uint8_t* y, const uint8_t* z, const uint8_t* x, uint8_t* out);
+int bp_ipp_fold_selftest(bp_ctx* ctx, uint32_t n, const uint8_t* ls, const uint8_t* rs, const uint8_t* hscale,
+                         const uint8_t* ub, uint32_t rounds, const uint8_t* xs, uint8_t* out);
 
 /* ---- decimal `show` digits on the device (self-test hook of the verifier's text path) ----
  * The transcript hashes `show` text of points and scalars (`pointToBS = show`, Utils.hs:32-33,145-174).  The

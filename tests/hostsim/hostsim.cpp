@@ -173,3 +173,69 @@ extern "C" size_t hs_show_point_rec(int style, const uint8_t* recs, char* out) {
 extern "C" size_t hs_show_point(int style, const uint8_t* pt, char* out) {
   return bp::host::show_point((bp::host::ShowStyle)style, pt, out);
 }
+
+// ---- frvec.h: the per-element bodies of the scalar-field vector kernels (frvec.hip), run serially ---------------
+#include "../../bulletproofs_amd/csrc/frvec.h"
+// canonical bytes in / out; Montgomery form inside, as on the device
+static u256 ldm(const uint8_t* p) { return fr_from_plain(ld(p)); }
+static void stm(uint8_t* p, const u256& a) { st(p, Fr::from_mont(a)); }
+extern "C" void hs_power_vector(const uint8_t* a, uint32_t n, uint8_t* out) {
+  u256 am = ldm(a);
+  for (uint32_t i = 0; i < n; i++) stm(out + 32 * (size_t)i, fr_power_elem(am, i));
+}
+extern "C" void hs_rp_polys(uint32_t n_bits, uint32_t nm, const uint8_t* bits, const uint8_t* s_r, const uint8_t* y,
+                            const uint8_t* z, uint8_t* l0, uint8_t* r0, uint8_t* r1) {
+  u256 ym = ldm(y), zm = ldm(z);
+  for (uint32_t i = 0; i < nm; i++) {
+    RpPolyElem e = rp_poly_elem(i, n_bits, bits[i], ldm(s_r + 32 * (size_t)i), ym, zm);
+    stm(l0 + 32 * (size_t)i, e.l0);
+    stm(r0 + 32 * (size_t)i, e.r0);
+    stm(r1 + 32 * (size_t)i, e.r1);
+  }
+}
+// one k_ipp_witness (fold part) + k_ipp_scalars pass over host arrays.  ls, rs: n canonical scalars (first nk_prev
+// live), folded in place when fold != 0; cg, ch: n plain coefficients, updated in place; sc: [3][2n + 1][32] out
+// (the bH entries are left untouched).
+extern "C" void hs_ipp_round(uint32_t n, uint32_t nk_prev, int fold, const uint8_t* x, const uint8_t* xi, uint8_t* ls,
+                             uint8_t* rs, uint8_t* cg, uint8_t* ch, uint8_t* sc) {
+  std::vector<u256> l(n), r(n);
+  for (uint32_t i = 0; i < nk_prev; i++) {
+    l[i] = ldm(ls + 32 * (size_t)i);
+    r[i] = ldm(rs + 32 * (size_t)i);
+  }
+  u256 xm = ldm(x), xim = ldm(xi);
+  uint32_t nk = nk_prev;
+  if (fold) {
+    nk = nk_prev / 2;
+    for (uint32_t j = 0; j < nk; j++) ipp_fold_elem(l[j], l[nk + j], r[j], r[nk + j], xm, xim);
+  }
+  const size_t nt = (size_t)2 * n + 1;
+  for (uint32_t i = 0; i < n; i++) {
+    u256 g = ld(cg + 32 * (size_t)i), h = ld(ch + 32 * (size_t)i);
+    if (fold) ipp_coeff_elem(i, nk_prev, g, h, xm, xim);
+    st(cg + 32 * (size_t)i, g);
+    st(ch + 32 * (size_t)i, h);
+    IppScalars s = ipp_scalar_elem(i, nk, g, h, [&](uint32_t j) { return l[j]; }, [&](uint32_t j) { return r[j]; });
+    st(sc + 32 * (size_t)i, s.c_g);
+    st(sc + 32 * ((size_t)n + i), s.c_h);
+    st(sc + 32 * (nt + i), s.l_g);
+    st(sc + 32 * (nt + n + i), s.l_h);
+    st(sc + 32 * (2 * nt + i), s.r_g);
+    st(sc + 32 * (2 * nt + n + i), s.r_h);
+  }
+  for (uint32_t i = 0; i < nk; i++) {
+    stm(ls + 32 * (size_t)i, l[i]);
+    stm(rs + 32 * (size_t)i, r[i]);
+  }
+}
+// mkOtherExponents for n = 2^lg; challenges: k canonical scalars in ROUND order, k >= lg
+extern "C" void hs_other_exponents(uint32_t lg, uint32_t k, const uint8_t* challenges, uint8_t* out) {
+  u256 c2_rev[24], prod = Fr::one();
+  for (uint32_t j = 0; j < k; j++) {
+    u256 c = ldm(challenges + 32 * (size_t)(k - 1 - j));
+    prod = Fr::mul(prod, c);
+    if (j < 24) c2_rev[j] = Fr::sqr(c);
+  }
+  u256 s0 = Fr::inv(prod);
+  for (uint32_t i = 0; i < (1u << lg); i++) stm(out + 32 * (size_t)i, ipp_other_exponent(i, lg, s0, c2_rev));
+}

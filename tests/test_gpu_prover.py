@@ -137,3 +137,84 @@ def test_prove_many_verify_batch(eng_gens):
         exp.append(i % 3 != 2)
     sc, pts, _ = pack_batch(proofs, vcs, m)
     assert eng_gens.verify_batch(n, m, len(proofs), sc, pts) == exp
+
+
+# ---- IPP.verifyProof on a caller-supplied base (InnerProductProof/Verifier.hs:18-73) -------------------------------
+def _ipp_instance(engine, rng, n):
+    ks = [rng.randrange(1, R) for _ in range(2 * n + 1)]
+    pts = engine.mul([o.GEN] * (2 * n + 1), ks)
+    b_gs, b_hs, b_h = pts[:n], pts[n:2 * n], pts[2 * n]
+    ls = [rng.randrange(R) for _ in range(n)]
+    rs = [rng.randrange(R) for _ in range(n)]
+    P = engine.sum_exps(ls + rs + [o.dot(ls, rs) if n else 0], b_gs + b_hs + [b_h])
+    return b_gs, b_hs, b_h, ls, rs, P
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 32])
+def test_ipp_verify_vs_oracle(engine, n):
+    """Honest proofs from the ORACLE's prover, then mutated l, swapped L/R, a wrong commitment and a wrong base:
+    the verdict equals the oracle's ipp_verify_proof each time."""
+    rng = random.Random(4300 + n)
+    b_gs, b_hs, b_h, ls, rs, P = _ipp_instance(engine, rng, n)
+    proof = o.ipp_generate_proof(b_gs, b_hs, b_h, P, ls, rs)
+    cases = [("honest", b_gs, b_hs, b_h, P, proof),
+             ("l+1", b_gs, b_hs, b_h, P, dict(proof, l=(proof["l"] + 1) % R)),
+             ("P+G", b_gs, b_hs, b_h, o.point_add(P, o.GEN), proof),
+             ("wrong bH", b_gs, b_hs, o.GEN, P, proof)]
+    if n >= 2:
+        cases.append(("swap L/R", b_gs, b_hs, b_h, P, dict(proof, lCommits=proof["rCommits"], rCommits=proof["lCommits"])))
+        cases.append(("Gs rotated", b_gs[1:] + b_gs[:1], b_hs, b_h, P, proof))
+        cases.append(("L_0 = O", b_gs, b_hs, b_h, P, dict(proof, lCommits=[o.O] + proof["lCommits"][1:])))
+    for name, g, h, u, p, pr in cases:
+        exp = o.ipp_verify_proof(n, g, h, u, p, pr)
+        assert engine.ipp_verify(n, g, h, u, p, pr) == exp, name
+        assert exp == (name == "honest")
+
+
+def test_ipp_verify_1024_generators(engine):
+    """n = 1024 (the size of config 2's inner-product argument) on a random caller-supplied base: proof from
+    bp_ipp_prove (itself oracle-checked at smaller n), verdicts of the honest and a mutated proof against the oracle."""
+    rng = random.Random(4400)
+    n = 1024
+    b_gs, b_hs, b_h, ls, rs, P = _ipp_instance(engine, rng, n)
+    proof = engine.ipp_prove(b_gs, b_hs, b_h, P, ls, rs)
+    assert len(proof["lCommits"]) == 10
+    assert engine.ipp_verify(n, b_gs, b_hs, b_h, P, proof) is True
+    assert o.ipp_verify_proof(n, b_gs, b_hs, b_h, P, proof) is True
+    bad = dict(proof, r=(proof["r"] + 1) % R)
+    assert engine.ipp_verify(n, b_gs, b_hs, b_h, P, bad) is False
+    bad2 = dict(proof, rCommits=proof["rCommits"][:5] + [o.GEN] + proof["rCommits"][6:])
+    assert engine.ipp_verify(n, b_gs, b_hs, b_h, P, bad2) is False
+
+
+def test_ipp_verify_reference_edge_semantics(engine):
+    """What the reference's lists do at the edges: n = 0 (one exponent, empty sums), n not a power of two (the Map walk
+    of mkOtherExponents leaves keys out), bases shorter than n (`sumExps` truncates, Utils.hs:79), more rounds than
+    logBase2 n, and fewer (the reference's `!!` fails: BP_ERR_ARG)."""
+    rng = random.Random(4500)
+    pts = engine.mul([o.GEN] * 20, [rng.randrange(1, R) for _ in range(20)])
+    b_gs, b_hs, b_h = pts[:8], pts[8:16], pts[16]
+    empty = dict(lCommits=[], rCommits=[], l=0, r=0)
+    for P in (o.O, o.GEN):
+        assert engine.ipp_verify(0, [], [], b_h, P, empty) == o.ipp_verify_proof(0, [], [], b_h, P, empty) == (P is o.O)
+    # arbitrary (dishonest) proofs: only the verdict's agreement with the oracle matters
+    for n, ng, nh, k in [(3, 8, 8, 1), (6, 8, 8, 2), (5, 3, 2, 3), (8, 5, 8, 3), (8, 8, 8, 4), (4, 8, 8, 3), (1, 1, 1, 2)]:
+        pr = dict(lCommits=pts[:k], rCommits=pts[3:3 + k], l=rng.randrange(R), r=rng.randrange(R))
+        exp = o.ipp_verify_proof(n, b_gs[:ng], b_hs[:nh], b_h, pts[17], pr)
+        assert engine.ipp_verify(n, b_gs[:ng], b_hs[:nh], b_h, pts[17], pr) == exp
+    # positive cases at the edge: n = 1 without rounds, where cProof = l*G_0 + r*H_0 + (l r)*bH has no challenge in it;
+    # empty base lists drop their term (sumExps [s] [] = O)
+    l1, r1 = rng.randrange(1, R), rng.randrange(1, R)
+    for ng, nh in [(1, 1), (0, 1), (1, 0), (0, 0)]:
+        P = o.point_mul(b_h, l1 * r1 % R)
+        if ng:
+            P = o.point_add(P, o.point_mul(b_gs[0], l1))
+        if nh:
+            P = o.point_add(P, o.point_mul(b_hs[0], r1))
+        pr = dict(lCommits=[], rCommits=[], l=l1, r=r1)
+        assert o.ipp_verify_proof(1, b_gs[:ng], b_hs[:nh], b_h, P, pr) is True
+        assert engine.ipp_verify(1, b_gs[:ng], b_hs[:nh], b_h, P, pr) is True
+        assert engine.ipp_verify(1, b_gs[:ng], b_hs[:nh], b_h, o.point_add(P, o.GEN), pr) is False
+    # fewer rounds than logBase2 n: `challenges !! j` fails in the reference
+    with pytest.raises(_lib.BpError):
+        engine.ipp_verify(8, b_gs, b_hs, b_h, pts[17], dict(lCommits=pts[:2], rCommits=pts[2:4], l=1, r=1))

@@ -224,3 +224,93 @@ def test_paired_sha256_and_decimal_writer(hs):
     for v in vals:
         n = hs.hs_u256_to_dec(v.to_bytes(32, "little"), out)
         assert out.raw[:n] == str(v).encode(), v
+
+
+# ---- frvec.h: the element bodies of the scalar-field vector kernels ----------------------------
+def _vec(vals):
+    return b"".join(b(v) for v in vals)
+
+
+def _unvec(raw, n):
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+
+def test_power_vector_incl_zero_quirk(hs):
+    """powerVector (Utils.hs:50-52): a^i, and all zeros for a = 0 (0^0 = 0 there)."""
+    rng = random.Random(801)
+    for a in (0, 1, 2, R - 1, rng.randrange(R)):
+        out = ctypes.create_string_buffer(32 * 70)
+        hs.hs_power_vector(b(a), 70, out)
+        assert _unvec(out.raw, 70) == o.power_vector(a, 70)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (4, 2), (8, 4), (64, 1), (16, 8)])
+def test_rp_polys_match_compute_lr_polys(hs, n, m):
+    """computeLRPolys (MultiRangeProof/Prover.hs:133-154) element by element."""
+    rng = random.Random(810 + n + m)
+    vs = [rng.randrange(2**n) for _ in range(m)]
+    a_l = o.reversed_encode_bit_multi(n, vs)
+    a_r = o.complementary_vector(a_l)
+    nm = n * m
+    s_l = [rng.randrange(R) for _ in range(nm)]
+    s_r = [rng.randrange(R) for _ in range(nm)]
+    y, z = rng.randrange(1, R), rng.randrange(1, R)
+    l0, l1, r0, r1 = o.compute_lr_polys(n, m, a_l, a_r, s_l, s_r, y, z)
+    outs = [ctypes.create_string_buffer(32 * nm) for _ in range(3)]
+    hs.hs_rp_polys(n, nm, bytes(a_l), _vec(s_r), b(y), b(z), *outs)
+    assert _unvec(outs[0].raw, nm) == [v % R for v in l0]
+    assert _unvec(outs[1].raw, nm) == [v % R for v in r0]
+    assert _unvec(outs[2].raw, nm) == [v % R for v in r1]
+    assert l1 == s_l
+
+
+def test_ipp_round_bodies_match_oracle_trace(hs):
+    """Three rounds of generateProof' (InnerProductProof/Prover.hs:52-92) at n = 8 on a random base: the folded witness
+    equals the oracle's ls', rs'; the coefficient form reproduces the oracle's folded generators gs'', hs''; the
+    expanded scalars of the next round give the oracle's lCommit, rCommit and commitment."""
+    rng = random.Random(820)
+    n = 8
+    gs = [o.point_mul(o.GEN, rng.randrange(1, R)) for _ in range(n)]
+    hsv = [o.point_mul(o.GEN, rng.randrange(1, R)) for _ in range(n)]
+    hscale = [rng.randrange(1, R) for _ in range(n)]
+    hs_scaled = [o.point_mul(p, s) for p, s in zip(hsv, hscale)]
+    u = o.point_mul(o.GEN, rng.randrange(1, R))
+    ls = [rng.randrange(R) for _ in range(n)]
+    rs = [rng.randrange(R) for _ in range(n)]
+    P = o.point_add(o.point_add(o.sum_exps(ls, gs), o.sum_exps(rs, hs_scaled)), o.point_mul(u, o.dot(ls, rs)))
+    b_ls, b_rs = ctypes.create_string_buffer(_vec(ls), 32 * n), ctypes.create_string_buffer(_vec(rs), 32 * n)
+    cg = ctypes.create_string_buffer(_vec([1] * n), 32 * n)
+    ch = ctypes.create_string_buffer(_vec(hscale), 32 * n)
+    nt = 2 * n + 1
+    sc = ctypes.create_string_buffer(3 * nt * 32)
+    cur_g, cur_h, cur_l, cur_r, cur_p = gs, hs_scaled, ls, rs, P
+    nk, fold, x, xi = n, 0, 0, 0
+    while True:
+        hs.hs_ipp_round(n, nk, fold, b(x), b(xi), b_ls, b_rs, cg, ch, sc)
+        if fold:
+            nk //= 2
+        assert _unvec(b_ls.raw, nk) == [v % R for v in cur_l] and _unvec(b_rs.raw, nk) == [v % R for v in cur_r]
+        s = _unvec(sc.raw, 3 * nt)
+        sums = [o.point_add(o.sum_exps(s[q * nt:q * nt + n], gs), o.sum_exps(s[q * nt + n:q * nt + 2 * n], hsv))
+                for q in range(3)]
+        # commitment of the folded witness under the folded base (without the bH term)
+        assert sums[0] == o.point_add(o.sum_exps(cur_l, cur_g), o.sum_exps(cur_r, cur_h))
+        if nk == 1:
+            break
+        lc, rc, xo, g2, h2, l2, r2, p2 = o.ipp_round(cur_g, cur_h, u, cur_p, cur_l, cur_r)
+        h = nk // 2
+        assert o.point_add(sums[1], o.point_mul(u, o.dot(cur_l[:h], cur_r[h:]))) == lc
+        assert o.point_add(sums[2], o.point_mul(u, o.dot(cur_l[h:], cur_r[:h]))) == rc
+        cur_g, cur_h, cur_l, cur_r, cur_p = g2, h2, l2, r2, p2
+        fold, x, xi = 1, xo, pow(xo, -1, R)
+
+
+@pytest.mark.parametrize("lg,k", [(0, 0), (1, 1), (3, 3), (5, 5), (3, 5)])
+def test_other_exponents_closed_form(hs, lg, k):
+    """mkOtherExponents (InnerProductProof/Verifier.hs:55-73): the Map's first-insert-wins walk equals the
+    product over set bits, with `challenges` in reversed round order."""
+    rng = random.Random(830 + lg + 7 * k)
+    chal = [rng.randrange(1, R) for _ in range(k)]     # round order
+    out = ctypes.create_string_buffer(32 << lg)
+    hs.hs_other_exponents(lg, k, _vec(chal), out)
+    assert _unvec(out.raw, 1 << lg) == o.mk_other_exponents(1 << lg, chal[::-1])
