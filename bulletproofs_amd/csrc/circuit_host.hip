@@ -181,9 +181,9 @@ int ac_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t n2, uint32_t k, 
   u256 *aL = f.v[0], *aR = f.v[1], *aO = f.v[2], *sL = f.v[3], *sR = f.v[4], *zwL = f.v[5], *zwR = f.v[6], *zwO = f.v[7];
   u256 *l1 = f.v[8], *r0 = f.v[9], *r1 = f.v[10], *r3 = f.v[11];
   u256* hscale = f.v[5];  // after computePolynomials the zs . W vectors are dead
-  const uint32_t nterms = 2 * n2 + 1, nblk = (nterms + 255) / 256;
+  const uint32_t nterms = 2 * n2 + 1;
   const size_t tb_bytes = ((size_t)nterms * 4 + 255) & ~(size_t)255;
-  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + fb_msm_partials(ctx, 3, nterms) * sizeof(xyzz) > 4 * w.seg_cap * 64) {
     ctx->err = "ac_prove_dev: prover workspace too small";
     return BP_ERR_STATE;
   }

@@ -66,17 +66,30 @@ __device__ __forceinline__ xyzz wave_sum(xyzz v) {
   }
   return v;
 }
+// Sum over the first `width` lanes of a wave (width a power of two <= 64); lane 0 holds the result.  Each step is a
+// full XYZZ addition (~3,500 instructions) on the critical path, so sums over few values take few steps.
+__device__ __forceinline__ xyzz wave_sum_width(xyzz v, int width) {
+#pragma unroll 1
+  for (int d = width >> 1; d > 0; d >>= 1) {
+    xyzz o = shfl_down_xyzz(v, d);
+    v = xyzz_add(v, o);
+  }
+  return v;
+}
 // Sum over a workgroup of up to 1024 threads; thread 0 holds the result.
 // `lds` must hold blockDim.x/64 xyzz values.
 __device__ __forceinline__ xyzz block_sum(xyzz v, xyzz* lds) {
   int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   v = wave_sum(v);
+  if (nw == 1) return v;
   if (lane == 0) lds[wid] = v;
   __syncthreads();
   xyzz r = xyzz_inf();
   if (wid == 0) {
     if (lane < nw) r = lds[lane];
-    r = wave_sum(r);
+    int width = 1;
+    while (width < nw) width <<= 1;
+    r = wave_sum_width(r, width);  // log2(waves) steps, not six
   }
   __syncthreads();
   return r;

@@ -99,6 +99,8 @@ bool prover_vectors_on_device();
 // BP_PROVER_FOLD=1 keeps the provers on ipp_prove_core (device-side generator folds)
 bool prover_uses_fixed_base();
 // fbmsm.hip
+// XYZZ partial sums fb_msm_launch needs at d_partial for these dimensions
+size_t fb_msm_partials(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms);
 int fb_msm_launch(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms, const uint8_t* d_scalars, const uint32_t* d_term_base,
                   xyzz* d_partial, const uint8_t* d_offset, uint8_t* d_out);
 

@@ -259,10 +259,10 @@ int ipp_prove_core(bp_ctx* ctx, ProverWs& w, uint32_t n, const uint8_t u[64], co
 int fb_msm_host(bp_ctx* ctx, ProverWs& w, const std::vector<uint32_t>& term_base, uint32_t nmsm,
                 const std::vector<Fr4>* const* scalars, uint8_t* const* outs) {
   hipStream_t st = ctx->stream;
-  const uint32_t nterms = (uint32_t)term_base.size(), nblk = (nterms + 255) / 256;
+  const uint32_t nterms = (uint32_t)term_base.size();
   BP_REQUIRE(nmsm >= 1 && nmsm <= 15 && nterms >= 1, "fb_msm_host: 1..15 sums over at least one term");
   const size_t tb_bytes = ((size_t)nterms * 4 + 255) & ~(size_t)255;
-  if ((size_t)nmsm * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + (size_t)nmsm * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+  if ((size_t)nmsm * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + fb_msm_partials(ctx, nmsm, nterms) * sizeof(xyzz) > 4 * w.seg_cap * 64) {
     ctx->err = "fb_msm_host: prover workspace too small";
     return BP_ERR_STATE;
   }
@@ -309,10 +309,10 @@ int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<Fr4>
     fr_to_bytes(rs[0], r_out);
     return BP_OK;
   }
-  const uint32_t nterms = 2 * n + 1, nblk = (nterms + 255) / 256;
+  const uint32_t nterms = 2 * n + 1;
   // device scratch out of the prover workspace: scalars in w.sc, base indices + partial sums in w.pts
   if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 ||
-      (((size_t)nterms * 4 + 255) & ~(size_t)255) + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+      (((size_t)nterms * 4 + 255) & ~(size_t)255) + fb_msm_partials(ctx, 3, nterms) * sizeof(xyzz) > 4 * w.seg_cap * 64) {
     ctx->err = "ipp_prove_fixed: prover workspace too small";
     return BP_ERR_STATE;
   }
@@ -495,9 +495,9 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
     ctx->err = "ipp_prove_fixed_dev: n must be a power of two within the context's generators and the workspace";
     return BP_ERR_ARG;
   }
-  const uint32_t nterms = 2 * n + 1, nblk = (nterms + 255) / 256;
+  const uint32_t nterms = 2 * n + 1;
   if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 ||
-      (((size_t)nterms * 4 + 255) & ~(size_t)255) + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+      (((size_t)nterms * 4 + 255) & ~(size_t)255) + fb_msm_partials(ctx, 3, nterms) * sizeof(xyzz) > 4 * w.seg_cap * 64) {
     ctx->err = "ipp_prove_fixed_dev: prover workspace too small";
     return BP_ERR_STATE;
   }
@@ -600,9 +600,9 @@ static int rangeproof_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t m
   u256 *l0 = f.v[0], *r0 = f.v[1], *r1 = f.v[2], *l1 = f.v[3], *sRm = f.v[4], *hscale = f.v[5];
   uint8_t* raw_sL = f.raw;
   uint8_t* raw_sR = f.raw + (size_t)nm * 32;
-  const uint32_t nterms = 2 * nm + 1, nblk = (nterms + 255) / 256;
+  const uint32_t nterms = 2 * nm + 1;
   const size_t tb_bytes = ((size_t)nterms * 4 + 255) & ~(size_t)255;
-  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + (size_t)3 * nblk * sizeof(xyzz) > 4 * w.seg_cap * 64) {
+  if ((size_t)3 * nterms * 32 > 4 * w.seg_cap * 32 || tb_bytes + fb_msm_partials(ctx, 3, nterms) * sizeof(xyzz) > 4 * w.seg_cap * 64) {
     ctx->err = "rangeproof_prove_dev: prover workspace too small";
     return BP_ERR_STATE;
   }
