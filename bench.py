@@ -2,16 +2,21 @@
 """bench.py - headline benchmark of the MI355X engine (BASELINE.json metric:
 "range-proof verifies/sec (64-bit, batched) at 1/2/4/8 GPU; MSM points/sec").
 
-One step = one pass of the batch verifier over one batch of synthetic proofs:
-config 4 of BASELINE.json, 65,536 independent 64-bit range proofs (m = 1), 1 % of them
-corrupted, per GPU (weak scaling: every rank verifies its own 65,536; proofs are independent,
-so there is no data-path collective - only the timing barrier).  The proofs are resident in
-HBM (and in pinned host memory for the host-side Fiat-Shamir hashing, which is part of the
-timed region) before the clock starts.  Per-proof verdicts are checked against the expected
-ones after every run, and at N = 1 against the C restatement of the reference on a sample.
+One step = one pass of the batch verifier over one batch of synthetic proofs: config 4 of BASELINE.json, 65,536
+independent 64-bit range proofs (m = 1), 1 % of them corrupted.  The proofs are resident in HBM (and in pinned host
+memory for the host-side Fiat-Shamir hashing, which is part of the timed region) before the clock starts.  Per-proof
+verdicts are checked against the expected ones after every run, and at N = 1 against the C restatement of the
+reference on a sample.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: proofs are independent, so ranks share nothing on the data path (only the timing barrier).  The headline
+`value` is WEAK scaling (every GPU verifies its own 65,536 proofs: per-GPU work is fixed, as the bench contract
+prescribes for a path that shards without a collective); `--scaling strong` makes the headline BASELINE config 4 as
+literally stated (the 65,536 proofs SPLIT over the N GPUs), and with the default the same split is measured next to the
+headline and reported under "strong_split".  The MSM leg (config 3) shards the point range over the ranks, keeps every
+shard resident in HBM and all-gathers the 64-byte partial sums over RCCL.
 """
 import argparse
 import ctypes
@@ -26,7 +31,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
 
 # more hardware queues than HIP's default of 4, before anything initialises the HIP runtime: the verifier's
-# chunk streams only overlap when they share a hardware pipe (bulletproofs_amd/csrc/ctx.hip)
+# chunk streams only overlap when they share a hardware pipe (bulletproofs_amd/csrc/ctx.hip).  The library itself
+# never touches the environment; this harness does, unless BP_KEEP_HW_QUEUES is set.
 if not os.environ.get("BP_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
     os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
@@ -34,6 +40,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from bulletproofs_amd import Engine, _lib  # noqa: E402
+from bulletproofs_amd import dist as bpdist  # noqa: E402
 import proofgen  # noqa: E402
 
 # gfx950 integer-VALU roofline: v_mad_u64_u32 issues at 16 lanes/clk/SIMD (measured 4.6 cycles per
@@ -41,6 +48,11 @@ import proofgen  # noqa: E402
 PEAK_TMAD = 256 * 4 * 16 * 2.4e9 / 1e12
 MADS_PER_MODMUL = 136   # 8-limb Montgomery CIOS, 2*8^2 + 8
 MODMUL_PER_MADD = 10    # XYZZ mixed addition, 8M + 2S
+MODMUL_PER_ADD = 14     # full addition
+MODMUL_PER_DBL = 10     # doubling
+GLV_BITS = 129
+GX = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+GY = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
 
 
 def corrupt(sc, pts, k, rng):
@@ -109,36 +121,149 @@ def cpu_baseline(sc, pts, n_bits, sample, gpu_verdicts):
     return res
 
 
-def msm_probe(eng, logn, iters):
-    """Secondary metric: MSM points/s for N = 2^logn (BASELINE.json config 3), device-resident."""
-    n = 1 << logn
-    rng = np.random.default_rng(3)
+# ---- config 3: MSM ----------------------------------------------------------------------------------------------
+def msm_choose_c(n):
+    """msm_core.h msm_choose_c."""
+    for lim, c in ((32, 4), (128, 5), (512, 7), (2048, 8), (8192, 10), (32768, 11), (131072, 13), (524288, 14)):
+        if n < lim:
+            return c
+    return 16
+
+
+def msm_algorithmic_mads(n_local, direct_max=65536):
+    """SURVEY.md 8(d) accounting for the path a local MSM of n_local terms takes.  Bucket method with GLV halves:
+    every point enters twice with a 129-bit half-scalar, W = ceil(130 / c) windows of c bits:
+    modmuls = 2 n W 10 (bucket accumulation) + W 2^(c-1) 2 14 (running-sum reduction) + 128 10 (window doublings).
+    Direct path (n <= 65,536): one 129-step GLV double-and-add per term."""
+    if n_local <= direct_max:
+        mm = n_local * (GLV_BITS * MODMUL_PER_DBL + GLV_BITS * 0.75 * MODMUL_PER_MADD)
+        return mm * MADS_PER_MODMUL, dict(path="direct", steps=GLV_BITS)
+    c = msm_choose_c(n_local)
+    W = (GLV_BITS + 1 + c - 1) // c
+    mm = 2 * n_local * W * MODMUL_PER_MADD + W * (1 << (c - 1)) * 2 * MODMUL_PER_ADD + 128 * MODMUL_PER_DBL
+    return mm * MADS_PER_MODMUL, dict(path="bucket", c=c, windows=W, glv=True)
+
+
+def make_points(eng, n, seed):
+    """n points k_i * G with seeded k_i (cheap derivation, points uploaded once)."""
+    rng = np.random.default_rng(seed)
     ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     ks[:, 31] &= 0x7F
-    G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
-         0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
-    g = np.frombuffer(_lib.enc_point(G), dtype=np.uint8)
+    g = np.frombuffer(_lib.enc_point((GX, GY)), dtype=np.uint8)
     pts = np.frombuffer(eng.point_mul_raw(ks.tobytes(), np.tile(g, n).tobytes(), n), dtype=np.uint8)
-    es = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-    es[:, 31] &= 0x7F
-    d_s = torch.from_numpy(es.copy()).cuda()
-    d_p = torch.from_numpy(pts.copy()).cuda()
-    d_o = torch.zeros(64, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, d_o.data_ptr())
-    eng.sync()
-    eng.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, d_o.data_ptr())
-    eng.sync()
-    dt = (time.perf_counter() - t0) / iters
-    ms, calls, madds = eng.profile_read(1)
-    eng.profile(False)
-    out = dict(n=n, ms=dt * 1e3, points_per_s=n / dt)
-    if calls:
-        out["k_light"] = dict(avg_ms=ms / calls, tmad_per_s=madds * MODMUL_PER_MADD * MADS_PER_MODMUL / (ms * 1e-3) / 1e12)
+    return ks, pts.copy()
+
+
+def make_scalars(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    es = np.zeros((n, 32), dtype=np.uint8)
+    if kind == "uniform":
+        es[:] = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        es[:, 31] &= 0x7F
+    elif kind == "64bit":
+        es[:, :8] = rng.integers(0, 256, size=(n, 8), dtype=np.uint8)
+    else:  # "01": the shape commitBitVectors sees for aL
+        es[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint8)
+    return es
+
+
+def msm_bench(eng, rank, world, dist, logns, iters):
+    """MSM points/s for N = 2^logn total points sharded over the ranks by contiguous ranges (each shard resident in
+    its GPU's HBM), scalars uniform / 64-bit / {0,1}.  `points_per_s` INCLUDES the upload of the scalars from pinned
+    host memory every iteration and EXCLUDES the one-time point upload; the resident-scalar
+    rate is reported next to it for the uniform case."""
+    R = _lib.R_ORDER
+    out = []
+    nmax = 1 << max(logns)
+    lo_max, hi_max = bpdist.shard_range(nmax, rank, world)
+    ks_all, pts_all = make_points(eng, hi_max - lo_max, 3 + 100 * rank)
+    d_pts_all = torch.from_numpy(pts_all).cuda()
+    d_out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gathered = torch.empty((world, 64), dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for logn in logns:
+        n = 1 << logn
+        lo, hi = bpdist.shard_range(n, rank, world)
+        nl = hi - lo
+        d_p = d_pts_all[:nl * 64]
+        mads, how = msm_algorithmic_mads(nl)
+        row = dict(n=n, n_per_gpu=nl, **how)
+        for kind in ("uniform", "64bit", "01"):
+            es = make_scalars(kind, nl, 30 + logn + 1000 * rank)
+            h_s = torch.from_numpy(es).pin_memory()
+            d_s = torch.empty_like(h_s, device="cuda")
+
+            def once(upload):
+                if upload:
+                    d_s.copy_(h_s, non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                bpdist.sharded_msm_dev(eng, d_s, d_p, nl, d_out, gathered=gathered)
+                eng.sync()
+            once(True)
+            if kind == "uniform" and logn == min(logns) and n <= (1 << 17):
+                # known discrete logs: sum e_i k_i * G must be the result (all ranks' shards together)
+                e_int = [int.from_bytes(bytes(r_), "little") for r_ in es]
+                k_int = [int.from_bytes(bytes(r_), "little") for r_ in ks_all[:nl]]
+                s = sum(a * b for a, b in zip(e_int, k_int)) % R
+                if dist is not None:
+                    parts = [None] * world
+                    dist.all_gather_object(parts, s)
+                    s = sum(parts) % R
+                exp = eng.mul([(GX, GY)], [s])[0]
+                got = _lib.dec_point(bytes(d_out.cpu().numpy()))
+                if got != exp:
+                    raise SystemExit("PARITY FAILURE: MSM result differs from (sum e_i k_i) * G at N = 2^%d" % logn)
+                row["checked"] = "result == (sum e_i k_i mod r) * G"
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                once(True)
+            barrier()
+            dt = (time.perf_counter() - t0) / iters
+            if dist is not None:
+                tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dt = float(tm.item())
+            ach = world * mads / dt / 1e12
+            row[kind] = dict(ms=dt * 1e3, points_per_s=n / dt, tmad_per_s=ach, frac=ach / (world * PEAK_TMAD))
+            if kind == "uniform":
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    once(False)
+                barrier()
+                dr = (time.perf_counter() - t0) / iters
+                row[kind]["resident_ms"] = dr * 1e3
+                row[kind]["resident_points_per_s"] = n / dr
+        out.append(row)
     return out
+
+
+def single_proof_configs(iters):
+    """BASELINE configs 1, 2, 5 (single proofs: latency) through the C ABI, host buffers in and out."""
+    import contextlib
+    import io
+    import config_bench
+    eng = Engine(torch.cuda.current_device())
+    lib = eng.lib
+    buf = io.StringIO()
+    try:
+        _, _, h = eng.derive_generators(4096)
+        import random
+        with contextlib.redirect_stdout(buf):
+            config_bench.range_config(eng, lib, "config1_rangeproof_64", 64, [(7238283, 827361)], 1, iters, h)
+            rng = random.Random(2)
+            vs = [(rng.randrange(0, 2**64), rng.randrange(1, _lib.R_ORDER)) for _ in range(16)]
+            config_bench.range_config(eng, lib, "config2_rangeproof_64x16", 64, vs, 2, iters, h)
+            config_bench.circuit_config(eng, lib, 4096, iters, h)
+    finally:
+        eng.close()
+    return [json.loads(line) for line in buf.getvalue().splitlines() if line.strip()]
 
 
 def main():
@@ -146,12 +271,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="proofs per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="proofs of the job (strong) / per GPU (weak)")
+    ap.add_argument("--scaling", choices=("auto", "strong", "weak"), default="auto",
+                    help="auto = weak (the headline); the split of BASELINE config 4 is then reported as strong_split")
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=192, help="proofs of the batch timed on the CPU restatement (~16 s on one core)")
-    ap.add_argument("--msm-logn", type=int, default=20)
+    ap.add_argument("--msm-logn", type=int, default=20, help="largest MSM size 2^k of the config-3 leg (0 = skip)")
+    ap.add_argument("--msm-min-logn", type=int, default=16)
+    ap.add_argument("--extras", type=int, default=1, help="single-proof configs and API-inclusive rates at N = 1")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +294,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    scaling = a.scaling if a.scaling != "auto" else "weak"
 
     def barrier():
         torch.cuda.synchronize()
@@ -174,7 +304,12 @@ def main():
 
     eng = Engine(local_rank)
     _, _, h = eng.derive_generators(a.bits)
-    B, n_bits = a.batch, a.bits
+    n_bits = a.bits
+    if scaling == "strong":
+        lo, hi = bpdist.shard_range(a.batch, rank, world)
+        B, total = hi - lo, a.batch
+    else:
+        B, total = a.batch, a.batch * world
     k = n_bits.bit_length() - 1
     gen_threads = min(16, os.cpu_count() or 1)
     inputs = proofgen.random_inputs(4 + 1000 * rank, n_bits, B)  # seed 4
@@ -208,6 +343,7 @@ def main():
     # k_fixed_multiexp launch above includes time shared with other chunks' kernels.  One extra untimed
     # pass with a single chunk gives the same kernel's duration with the GPU to itself.
     iso = None
+    api = None
     if rank == 0:
         job1 = eng.vjob(n_bits, 1, B, 1, a.host_threads)
         job1.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
@@ -217,13 +353,72 @@ def main():
         iso = eng.profile_read(0)
         eng.profile(False)
         job1.close()
+    if rank == 0 and world == 1 and a.extras:
+        # API-inclusive rates: (1) load + run from PAGEABLE host arrays (the proofs cross PCIe and are copied into
+        # pinned chunk buffers inside the timed region); (2) bp_rangeproof_verify_batch, what the Haskell shim
+        # calls: cold (creates the job: pinned staging, workspaces, hashing threads) and again (job cached on the context)
+        scp, ptp = sc.copy(), pts.copy()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            job.load(scp.ctypes.data_as(ctypes.c_char_p), ptp.ctypes.data_as(ctypes.c_char_p))
+            check(job.run())
+        dl = (time.perf_counter() - t0) / 3
+        scb, ptb = sc.tobytes(), pts.tobytes()
+        t0 = time.perf_counter()
+        v1 = eng.verify_batch(n_bits, 1, B, scb, ptb)
+        cold = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        v2 = eng.verify_batch(n_bits, 1, B, scb, ptb)
+        warm = time.perf_counter() - t0
+        if not (np.array(v1, dtype=np.uint8) == expected).all() or v1 != v2:
+            raise SystemExit("bp_rangeproof_verify_batch: verdicts differ from the expected ones")
+        api = dict(value_incl_load=B / dl, incl_load_ms=dl * 1e3,
+                   verify_batch_api=dict(cold_ms=cold * 1e3, cold_verifies_per_s=B / cold, warm_ms=warm * 1e3,
+                                         warm_verifies_per_s=B / warm,
+                                         what="bp_rangeproof_verify_batch from pageable host buffers: first call "
+                                              "(creates and caches the job on the context), then a second call"))
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    job.close()
+
+    # BASELINE config 4 as literally stated - the job's 65,536 proofs SPLIT over the GPUs - next to a weak headline
+    strong = None
+    if world > 1 and scaling == "weak":
+        lo, hi = bpdist.shard_range(a.batch, rank, world)
+        Bs = hi - lo
+        js = eng.vjob(n_bits, 1, Bs, a.chunks, a.host_threads)
+        scs, pts_s = np.ascontiguousarray(sc[:, :Bs]), np.ascontiguousarray(pts[:, :Bs])
+        # the wrong-V corruption points at the neighbouring proof's V, which the slice keeps except for its last proof
+        exp_s = expected[:Bs].copy()
+        js.load(scs.ctypes.data_as(ctypes.c_char_p), pts_s.ctypes.data_as(ctypes.c_char_p))
+        first = np.frombuffer(js.run(), dtype=np.uint8)
+        if not (first[:Bs - 1] == exp_s[:Bs - 1]).all():
+            raise SystemExit("rank %d: strong-split verdicts differ from the expected ones" % rank)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(3, a.steps // 2)):
+            js.run()
+        barrier()
+        ds = (time.perf_counter() - t0) / max(3, a.steps // 2)
+        tm = torch.tensor([ds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ds = float(tm.item())
+        js.close()
+        strong = dict(scaling="strong", proofs_total=a.batch, proofs_per_gpu=Bs, ms_per_step=ds * 1e3,
+                      value=a.batch / ds, unit="verifies/s",
+                      what="BASELINE configs[3] literally: the 65,536 proofs split over the GPUs; small per-GPU batches "
+                           "are bound by the serial challenge chain of a proof (6 rounds), not by throughput")
+
+    msm = None
+    if a.msm_logn > 0:
+        logns = list(range(min(a.msm_min_logn, a.msm_logn), a.msm_logn + 1))
+        msm = msm_bench(eng, rank, world, dist, logns, 5)
 
     if rank == 0:
-        value = world * B * a.steps / dt
+        value = total * a.steps / dt
+        hwq, pool, conc = eng.queue_info()
         line = {
             "metric": "range-proof verifies/sec (64-bit, batched)",
             "value": value,
@@ -233,19 +428,22 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE.json configs[3]: batch verification of %d independent %d-bit range proofs "
-                            "(m=1) per GPU, 1%% corrupted, per-proof verdicts checked; host Fiat-Shamir hashing "
-                            "inside the timed region" % (B, n_bits),
-                "proofs_per_gpu": B, "bits": n_bits, "m": 1,
+                            "(m=1)%s, 1%% corrupted, per-proof verdicts checked; host Fiat-Shamir hashing "
+                            "inside the timed region; proofs resident in HBM + pinned host memory when the clock starts"
+                            % (total, n_bits, " split over %d GPUs" % world if scaling == "strong" and world > 1 else
+                               (" per GPU x %d GPUs" % world if world > 1 else "")),
+                "proofs_total": total, "proofs_per_gpu": B, "bits": n_bits, "m": 1,
                 "host_threads": a.host_threads or int(os.environ.get("BP_HOST_THREADS", "0")) or
                 min(16, os.cpu_count() or 1),
                 "chunks": a.chunks or (4 if B >= 16384 else (2 if B >= 4096 else 1)),
                 "proofgen_s": gen_s,
+                "hw_queues_env": hwq, "stream_pool": pool, "concurrent_streams": conc,
             },
         }
         if fixed_calls:
@@ -275,13 +473,30 @@ def main():
                 line["roofline"]["traffic_source"] = t["source"]
                 if "valu_issue_util" in t:  # SQ_INSTS_VALU x 4 cycles against SIMD-cycles of the same launches
                     line["roofline"]["valu_issue_util"] = t["valu_issue_util"]
-        if world == 1:
-            if a.cpu_sample > 0:
-                line["cpu_baseline"] = cpu_baseline(sc, pts, n_bits, min(a.cpu_sample, B), got)
-            if a.msm_logn > 0:
-                line["msm"] = msm_probe(eng, a.msm_logn, 5)
+        if world == 1 and a.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(sc, pts, n_bits, min(a.cpu_sample, B), got)
+        if msm:
+            top = msm[-1]
+            line["msm"] = {
+                "metric": "MSM points/sec (secp256k1, BASELINE.json configs[2])",
+                "n": top["n"], "points_per_s": top["uniform"]["points_per_s"], "ms": top["uniform"]["ms"],
+                "frac": top["uniform"]["frac"],
+                "what": "sum e_i P_i, points resident (one-time upload excluded), scalars uploaded from pinned host "
+                        "memory every iteration (included), %d GPU(s) by contiguous point ranges + all-gather of "
+                        "64-byte partial sums; frac = SURVEY 8d algorithmic mads / (time x %d x %.1f Tmad/s)"
+                        % (world, world, PEAK_TMAD),
+                "sweep": msm,
+            }
+        if strong:
+            line["strong_split"] = strong
+        if api:
+            line["api_inclusive"] = api
+        if world == 1 and a.extras:
+            try:
+                line["extra"] = {"single_proof_configs": single_proof_configs(8)}
+            except Exception as e:  # never lose the headline line to a side measurement
+                line["extra"] = {"single_proof_configs_error": repr(e)}
         print(json.dumps(line), flush=True)
-    job.close()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

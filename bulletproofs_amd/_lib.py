@@ -54,6 +54,7 @@ SYMBOLS = {
     "bp_point_on_curve": (_int, [_vp, _u8p, _sz, _u8p]),
     "bp_msm": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "bp_point_sum_dev": (_int, [_vp, _vp, _sz, _vp]),
     "bp_msm_dev_static": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
     "bp_fr_vector_op": (_int, [_vp, _int, _u8p, _u8p, ctypes.c_uint32, _u8p]),
@@ -226,6 +227,9 @@ class Engine:
 
     def msm_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
         self._check(self.lib.bp_msm_dev(self.h, d_scalars, d_points, n, window_bits, d_out), "bp_msm_dev")
+
+    def point_sum_dev(self, d_points, n, d_out):
+        self._check(self.lib.bp_point_sum_dev(self.h, d_points, n, d_out), "bp_point_sum_dev")
 
     def msm_dev_static(self, d_scalars, d_points, n, d_out, window_bits=0):
         """bp_msm_dev over the library's static scratch array: no allocation (n <= 65,536)."""

@@ -132,6 +132,8 @@ void bp_ctx_destroy(bp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->vjob_cache && ctx->vjob_cache_free) ctx->vjob_cache_free(ctx->vjob_cache);
+  ctx->vjob_cache = nullptr;
   ctx->msm_ws.release();
   ctx->io.release();
   ctx->gen.release();

@@ -61,7 +61,8 @@ struct bp_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // generator state (filled by bp_ctx_set_generators); pointers into `gen`
-  uint32_t n_gens = 0;       // generator pairs (gs_i, hs_i)
+  uint32_t n_gens = 0;       // generator pairs (gs_i, hs_i); 0 = no generators installed
+  uint64_t gen_epoch = 0;    // bumped by every bp_ctx_set_generators: batch objects of an older set are refused
   uint32_t n_bases = 0;      // rows of d_bases: gs, hs, G, H, GS_k
   uint8_t* d_bases = nullptr;  // affine, 64 B each
   uint8_t* d_table = nullptr;  // fixed-base window table, see fixedbase.h
@@ -75,6 +76,9 @@ struct bp_ctx {
   // transcript conventions the reference inherits from un-vendored packages
   int show_style = 0;    // 0: derived Show "A (P x) (P y)" / "P s"; 1: plain "A x y" / "s"
   int sqrt_branch = 0;   // 0: sr returns a^((p+1)/4); 1: the other root
+  // the batch job bp_rangeproof_verify_batch keeps between calls of one shape (rangeproof_host.hip)
+  void* vjob_cache = nullptr;
+  void (*vjob_cache_free)(void*) = nullptr;
   // optional kernel timing with HIP events on the launching stream (bp_ctx_profile)
   int profile = 0;
   double prof_ms[2] = {0, 0};        // [0] k_fixed_multiexp, [1] k_light

@@ -81,6 +81,16 @@ __global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts
   }
 }
 
+// bad[0] += 1 for every entry that is not a finite point of the curve with canonical coordinates (< p)
+__global__ void __launch_bounds__(256) k_gen_check(const uint8_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine a = ld_affine(pts + (size_t)i * 64);
+  const u256 p = fq_p();
+  bool ok = !affine_is_inf(a) && !u256_geq(a.x, p) && !u256_geq(a.y, p) && affine_on_curve(a);
+  if (!ok) atomicAdd(bad, 1u);
+}
+
 // window width for a generator set: the widest whose table fits the budget (env BP_FB_WBITS forces one)
 static int choose_fb_wbits(uint32_t nbases) {
   if (const char* e = getenv("BP_FB_WBITS")) {
@@ -116,59 +126,107 @@ int bp_ctx_set_generators(bp_ctx* ctx, const uint8_t* gs, const uint8_t* hs, con
   while ((1u << nk) < n_gens) nk++;
   nk += 1;  // GS_k for k = 0..log2(n_gens)
   uint32_t nbases = 2 * n_gens + 2 + nk;
-  const int wb = choose_fb_wbits(nbases);
-  const uint32_t W = fb_windows(wb), E = fb_entries(wb);
-  const uint32_t blk = E < (uint32_t)FB_BUILD_BLOCK ? E : (uint32_t)FB_BUILD_BLOCK;
-  size_t nrows = (size_t)nbases * W;
-  size_t table_bytes = nrows * E * 64;
-  auto carve = [&](void* base) {
-    Carver c(base);
-    ctx->d_bases = c.take<uint8_t>((size_t)nbases * 64);
-    ctx->d_table = c.take<uint8_t>(table_bytes);
-    return c.off;
-  };
-  size_t need = carve(nullptr);
-  if (ctx->gen.reserve(need) != 0) {
-    ctx->err = "generator table allocation failed";
-    return BP_ERR_NOMEM;
+  // Whatever happens below, the previous generator set is gone (the table buffer is re-used or freed): the context
+  // holds NO generators until the new tables are complete, and batch objects created against the old set are
+  // refused from now on (they compare this epoch).
+  ctx->n_gens = 0;
+  ctx->n_bases = 0;
+  ctx->d_bases = nullptr;
+  ctx->d_table = nullptr;
+  ctx->gen_epoch++;
+  int wb = choose_fb_wbits(nbases);
+  const bool forced = getenv("BP_FB_WBITS") != nullptr;
+  uint32_t W = 0, E = 0, blk = 0;
+  size_t nrows = 0, table_bytes = 0, row_scratch = 0, slab_rows = 0, starts_bytes = 0;
+  uint8_t *d_bases = nullptr, *d_table = nullptr;
+  DevBuf tmp;
+  struct TmpGuard {
+    DevBuf& b;
+    ~TmpGuard() { b.release(); }
+  } tmp_guard{tmp};
+  for (;;) {  // on an allocation failure fall back to the next narrower window
+    W = fb_windows(wb);
+    E = fb_entries(wb);
+    blk = E < (uint32_t)FB_BUILD_BLOCK ? E : (uint32_t)FB_BUILD_BLOCK;
+    nrows = (size_t)nbases * W;
+    table_bytes = nrows * E * 64;
+    auto carve = [&](void* base) {
+      Carver c(base);
+      d_bases = c.take<uint8_t>((size_t)nbases * 64);
+      d_table = c.take<uint8_t>(table_bytes);
+      return c.off;
+    };
+    size_t need = carve(nullptr);
+    // temporary buffers for the build: window starts + XYZZ scratch for one slab of rows (<= 2 GiB)
+    row_scratch = (size_t)E * sizeof(xyzz);
+    slab_rows = ((size_t)2 << 30) / row_scratch;
+    if (slab_rows < 1) slab_rows = 1;
+    if (slab_rows > nrows) slab_rows = nrows;
+    starts_bytes = (nrows * sizeof(xyzz) + 255) & ~(size_t)255;
+    if (ctx->gen.reserve(need) == 0 && tmp.reserve(starts_bytes + slab_rows * row_scratch) == 0) {
+      carve(ctx->gen.p);
+      break;
+    }
+    tmp.release();
+    (void)hipGetLastError();  // clear the allocation error
+    if (forced || wb == 8) {
+      ctx->gen.release();
+      ctx->err = "generator table allocation failed";
+      return BP_ERR_NOMEM;
+    }
+    wb = wb == 20 ? 16 : (wb == 16 ? 12 : 8);
   }
-  carve(ctx->gen.p);
   hipStream_t st = ctx->stream;
   affine G = affine_gen();
-  BP_TRY(hipMemcpyAsync(ctx->d_bases, gs, (size_t)n_gens * 64, hipMemcpyHostToDevice, st));
-  BP_TRY(hipMemcpyAsync(ctx->d_bases + (size_t)n_gens * 64, hs, (size_t)n_gens * 64, hipMemcpyHostToDevice, st));
-  BP_TRY(hipMemcpyAsync(ctx->d_bases + (size_t)2 * n_gens * 64, &G, 64, hipMemcpyHostToDevice, st));
-  BP_TRY(hipMemcpyAsync(ctx->d_bases + (size_t)(2 * n_gens + 1) * 64, h, 64, hipMemcpyHostToDevice, st));
-  BP_TRY(hipStreamSynchronize(st));  // G lives on the host stack
-  hipLaunchKernelGGL(k_gsum, dim3(1), dim3(256), 0, st, ctx->d_bases, n_gens, nk,
-                     ctx->d_bases + (size_t)(2 * n_gens + 2) * 64);
-  // temporary buffers for the build: window starts + XYZZ scratch for one slab of rows (<= 2 GiB)
-  size_t row_scratch = (size_t)E * sizeof(xyzz);
-  size_t slab_rows = ((size_t)2 << 30) / row_scratch;
-  if (slab_rows < 1) slab_rows = 1;
-  if (slab_rows > nrows) slab_rows = nrows;
-  DevBuf tmp;
-  size_t starts_bytes = (nrows * sizeof(xyzz) + 255) & ~(size_t)255;
-  if (tmp.reserve(starts_bytes + slab_rows * row_scratch) != 0) {
-    ctx->err = "generator table scratch allocation failed";
-    return BP_ERR_NOMEM;
+  BP_TRY(hipMemcpyAsync(d_bases, gs, (size_t)n_gens * 64, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(d_bases + (size_t)n_gens * 64, hs, (size_t)n_gens * 64, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(d_bases + (size_t)2 * n_gens * 64, &G, 64, hipMemcpyHostToDevice, st));
+  BP_TRY(hipMemcpyAsync(d_bases + (size_t)(2 * n_gens + 1) * 64, h, 64, hipMemcpyHostToDevice, st));
+  {
+    hipError_t e0 = hipStreamSynchronize(st);  // G lives on the host stack
+    if (e0 != hipSuccess) {
+      ctx->err = std::string("generator upload: ") + hipGetErrorString(e0);
+      return BP_ERR_DEVICE;
+    }
   }
+  {
+    // gs, hs, gen, h replace group elements the reference computes itself: every entry must be a finite curve point
+    // in canonical encoding (the kernels' "d * B is never the identity" and the transcript text rely on it)
+    uint32_t* d_bad = (uint32_t*)tmp.p;
+    uint32_t bad = 0;
+    hipError_t e1 = hipMemsetAsync(d_bad, 0, 4, st);
+    hipLaunchKernelGGL(k_gen_check, dim3((2 * n_gens + 2 + 255) / 256), dim3(256), 0, st, d_bases, 2 * n_gens + 2, d_bad);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+    if (e1 != hipSuccess) {
+      ctx->err = std::string("generator check: ") + hipGetErrorString(e1);
+      return BP_ERR_DEVICE;
+    }
+    if (bad) {
+      ctx->err = "bp_ctx_set_generators: a generator is not a finite, canonically encoded point of the curve";
+      return BP_ERR_ARG;
+    }
+  }
+  hipLaunchKernelGGL(k_gsum, dim3(1), dim3(256), 0, st, d_bases, n_gens, nk,
+                     d_bases + (size_t)(2 * n_gens + 2) * 64);
   xyzz* starts = (xyzz*)tmp.p;
   xyzz* scratch = (xyzz*)((char*)tmp.p + starts_bytes);
-  hipLaunchKernelGGL(k_fb_starts, dim3((nbases + 255) / 256), dim3(256), 0, st, ctx->d_bases, nbases, wb, starts);
+  hipLaunchKernelGGL(k_fb_starts, dim3((nbases + 255) / 256), dim3(256), 0, st, d_bases, nbases, wb, starts);
   for (size_t r0 = 0; r0 < nrows; r0 += slab_rows) {
     uint32_t nr = (uint32_t)(nrows - r0 < slab_rows ? nrows - r0 : slab_rows);
     size_t nthreads = (size_t)nr * (E / blk);
     hipLaunchKernelGGL(k_fb_fill, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, starts, (uint32_t)r0, nr,
-                       E, blk, scratch, ctx->d_table);
+                       E, blk, scratch, d_table);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  tmp.release();
   if (e != hipSuccess) {
     ctx->err = std::string("generator table build: ") + hipGetErrorString(e);
     return BP_ERR_DEVICE;
   }
+  // commit: only a complete table becomes visible
+  ctx->d_bases = d_bases;
+  ctx->d_table = d_table;
   ctx->fb_wbits = wb;
   ctx->n_gens = n_gens;
   ctx->n_bases = nbases;

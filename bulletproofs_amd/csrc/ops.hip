@@ -53,6 +53,15 @@ __global__ void __launch_bounds__(256) k_add_two_mul(const uint8_t* __restrict__
   st_affine(out + (size_t)i * 64, xyzz_to_affine(acc));
 }
 
+// out = sum of n affine points; one workgroup (the per-GPU partial sums of a sharded MSM: n is the number of GPUs)
+__global__ void __launch_bounds__(256) k_point_sum(const uint8_t* __restrict__ pts, uint32_t n, uint8_t* __restrict__ out) {
+  __shared__ xyzz lds[4];
+  xyzz acc = xyzz_inf();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) acc = xyzz_madd(acc, ld_affine(pts + (size_t)i * 64));
+  xyzz r = block_sum(acc, lds);
+  if (threadIdx.x == 0) st_affine(out, xyzz_to_affine(r));
+}
+
 __global__ void __launch_bounds__(256) k_on_curve(const uint8_t* __restrict__ points, uint32_t n,
                                                  uint8_t* __restrict__ ok) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,6 +251,17 @@ int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t 
   BP_REQUIRE(window_bits >= 0 && window_bits <= 16, "window_bits must be 0 (auto) or 1..16");
   BP_TRY(hipSetDevice(ctx->device));
   return msm_run(ctx, d_scalars, d_points, n, window_bits, d_out, nullptr);
+}
+
+int bp_point_sum_dev(bp_ctx* ctx, const void* d_points, size_t n, void* d_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(d_out && (n == 0 || d_points), "null pointer");
+  BP_CHECK_N(n);
+  BP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_point_sum, dim3(1), dim3(n <= 64 ? 64 : 256), 0, ctx->stream, (const uint8_t*)d_points, (uint32_t)n,
+                     (uint8_t*)d_out);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
 }
 
 int bp_msm_dev_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,

@@ -410,14 +410,35 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
   return BP_OK;
 }
 
+// One job (workspaces in HBM, pinned staging, the hashing threads) stays cached on the context, so that repeated calls of
+// one shape - the shim's single-proof verifyProof in a loop, or `map verifyProof` batch after batch - do not
+// allocate and free pinned memory, device workspaces and a thread pool every time.  A call of another shape, new
+// generators or another `show` style replaces it; bp_ctx_destroy frees it.  BP_NO_VJOB_CACHE=1 turns the cache off.
+static void vjob_cache_free(void* j) { bp_vjob_destroy((bp_vjob*)j); }
+
 int bp_rangeproof_verify_batch(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, const uint8_t* scalars,
                                const uint8_t* points, uint8_t* verdicts) {
-  bp_vjob* job = nullptr;
-  int rc = bp_vjob_create(ctx, n_bits, m, batch, 0, 0, &job);
-  if (rc != BP_OK) return rc;
+  if (!ctx) return BP_ERR_ARG;
+  static const bool no_cache = getenv("BP_NO_VJOB_CACHE") && atoi(getenv("BP_NO_VJOB_CACHE")) != 0;
+  bp_vjob* job = (bp_vjob*)ctx->vjob_cache;
+  if (job && (no_cache || job->n_bits != n_bits || job->m != m || job->batch != batch ||
+              job->style != (ShowStyle)ctx->show_style || job->chunks[0].vb->epoch != ctx->gen_epoch)) {
+    bp_vjob_destroy(job);
+    job = nullptr;
+    ctx->vjob_cache = nullptr;
+  }
+  int rc;
+  if (!job) {
+    rc = bp_vjob_create(ctx, n_bits, m, batch, 0, 0, &job);
+    if (rc != BP_OK) return rc;
+    if (!no_cache) {
+      ctx->vjob_cache = job;
+      ctx->vjob_cache_free = vjob_cache_free;
+    }
+  }
   rc = bp_vjob_load(job, scalars, points);
   if (rc == BP_OK) rc = bp_vjob_run(job, verdicts);
-  bp_vjob_destroy(job);
+  if (no_cache) bp_vjob_destroy(job);
   return rc;
 }
 

@@ -50,6 +50,8 @@ struct bp_vbatch {
   bool begun_complete;    // the begin stage has been waited for (its constants are complete)
   // device
   uint8_t *sc, *pts, *chal, *xk, *acc_aff, *vs, *verdict;
+  uint8_t* bad;           // per proof: the loaded encoding was invalid (k_vcheck); such a proof does not verify
+  uint64_t epoch;         // ctx->gen_epoch at creation: the generator set the term tables refer to
   bp::u256 *cst, *ypowinv, *zpow, *xk_m /* x_k^2 */, *xkinv_m, *stab /* half-tables of the s-vector */;
   uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
   bp::xyzz *acc1, *acc2, *vtab, *vtab2;  // vtab2: joint tables of the t-check (runs beside the rounds)

@@ -677,14 +677,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   st_xyzz(&acc2[p], acc);
 }
 
-// verdict[p] = (acc1 == acc_k) && (acc2 == O)
+// Input validation at load time: bad[p] = 1 when proof p holds a point that is neither O nor a canonically encoded
+// (x, y < p) point of the curve, or a scalar >= r.  The reference's types cannot represent such values (Fq / Fr are
+// always reduced; an off-curve `A x y` would run through its affine formulas, for which no parity can be claimed);
+// here such a proof simply does not verify.  One thread per (row, proof); rows 0..4 are the scalar rows.
+__global__ void __launch_bounds__(256) k_vcheck(uint32_t B, uint32_t npts, const uint8_t* __restrict__ sc,
+                                               const uint8_t* __restrict__ pts, uint8_t* __restrict__ bad) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)(5 + npts) * B) return;
+  uint32_t row = (uint32_t)(t / B), p = (uint32_t)(t % B);
+  bool ok;
+  if (row < 5) {
+    ok = !u256_geq(ld_u256(sc + ((size_t)row * B + p) * 32), Fr::modulus());
+  } else {
+    affine a = ld_affine(pts + ((size_t)(row - 5) * B + p) * 64);
+    const u256 q = fq_p();
+    ok = affine_is_inf(a) || (!u256_geq(a.x, q) && !u256_geq(a.y, q) && affine_on_curve(a));
+  }
+  if (!ok) bad[p] = 1;
+}
+
+// verdict[p] = (acc1 == acc_k) && (acc2 == O) && the proof's encoding was valid
 __global__ void __launch_bounds__(256) k_verdict(VDims d, const xyzz* __restrict__ acc1, const xyzz* __restrict__ acc2,
-                                                const uint8_t* __restrict__ acc_aff, uint8_t* __restrict__ verdict,
+                                                const uint8_t* __restrict__ acc_aff, const uint8_t* __restrict__ bad,
+                                                uint8_t* __restrict__ verdict,
                                                 uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   xyzz e1 = xyzz_madd(ld_xyzz(&acc1[p]), affine_neg(ld_affine(acc_aff + (size_t)p * 64)));
-  bool ok = xyzz_is_inf(e1) && xyzz_is_inf(ld_xyzz(&acc2[p]));
+  bool ok = xyzz_is_inf(e1) && xyzz_is_inf(ld_xyzz(&acc2[p])) && bad[p] == 0;
   verdict[p] = ok ? 1 : 0;
   if (host_out) host_out[p] = ok ? 1 : 0;
 }
@@ -759,12 +780,19 @@ static inline void launch_tcheck(bp_vbatch* vb, hipStream_t strm) {
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
   bp_ctx* ctx = vb->ctx;
   size_t B = vb->d.B;
+  if (vb->epoch != ctx->gen_epoch) {
+    ctx->err = "the context's generators were replaced after this batch object was created: create a new one";
+    return BP_ERR_STATE;
+  }
   if (vb->tab_pending) {  // tables of the previous proofs
     BP_TRY(hipStreamSynchronize(vb->aux));
     vb->tab_pending = false;
   }
   BP_TRY(hipMemcpyAsync(vb->sc, scalars, 5 * B * 32, hipMemcpyHostToDevice, vb->stream));
   BP_TRY(hipMemcpyAsync(vb->pts, points, (size_t)vb->npts * B * 64, hipMemcpyHostToDevice, vb->stream));
+  BP_TRY(hipMemsetAsync(vb->bad, 0, B, vb->stream));
+  hipLaunchKernelGGL(k_vcheck, VB_GRID((size_t)(5 + vb->npts) * B), (uint32_t)B, vb->npts, vb->sc, vb->pts, vb->bad);
+  BP_TRY(hipGetLastError());
   vb->stage = 1;
   return BP_OK;
 }
@@ -809,6 +837,10 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   bp_ctx* ctx = vb->ctx;
   if (vb->stage < 1) {
     ctx->err = "bp_vbatch_begin before bp_vbatch_load";
+    return BP_ERR_STATE;
+  }
+  if (vb->epoch != ctx->gen_epoch) {
+    ctx->err = "the context's generators were replaced after this batch object was created: create a new one";
     return BP_ERR_STATE;
   }
   VDims d = vb->d;
@@ -925,7 +957,7 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
     launch_tcheck(vb, vb->stream);
   }
   uint8_t* direct = vb->direct_host ? verdicts : nullptr;
-  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->verdict, direct);
+  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->bad, vb->verdict, direct);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 1;  // may be begun again with the same loaded proofs
@@ -1009,6 +1041,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->acc_aff = c.take<uint8_t>(B * 64);
     vb->vs = c.take<uint8_t>((size_t)(m + 2) * B * 32);
     vb->verdict = c.take<uint8_t>(B);
+    vb->bad = c.take<uint8_t>(B);
     vb->cst = c.take<u256>((size_t)C_COUNT * B);
     vb->ypowinv = c.take<u256>((size_t)nm * B);
     vb->zpow = c.take<u256>((size_t)(m + 3) * B);
@@ -1083,6 +1116,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     return BP_ERR_DEVICE;
   }
   vb->stage = 0;
+  vb->epoch = ctx->gen_epoch;
   vb->direct_host = false;
   *out = vb;
   return BP_OK;

@@ -40,6 +40,27 @@ def sharded_msm(eng, scalars, points, n, group=None):
     return acc
 
 
+def sharded_msm_dev(eng, d_scalars, d_points, n_local, d_out, group=None, gathered=None):
+    """The same with every rank's shard RESIDENT ON ITS GPU: `d_scalars` / `d_points` are torch uint8 CUDA tensors
+    holding this rank's n_local scalars / points, `d_out` a 64-byte CUDA tensor that receives the total on every
+    rank.  One local bucket MSM, one all-gather of the 64-byte partial sums over RCCL (device to device, no host
+    round trip of the partials), one small kernel that adds the `world` points.  `gathered` may pass a reusable
+    [world, 64] CUDA tensor."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        eng.msm_dev(d_scalars.data_ptr(), d_points.data_ptr(), n_local, d_out.data_ptr())
+        return d_out
+    part = torch.empty(64, dtype=torch.uint8, device=d_out.device)
+    eng.msm_dev(d_scalars.data_ptr(), d_points.data_ptr(), n_local, part.data_ptr())
+    eng.sync()  # the engine runs on its own stream; the collective is ordered behind it from the host
+    if gathered is None:
+        gathered = torch.empty((world, 64), dtype=torch.uint8, device=d_out.device)
+    dist.all_gather_into_tensor(gathered, part, group=group)
+    torch.cuda.current_stream().synchronize()
+    eng.point_sum_dev(gathered.data_ptr(), world, d_out.data_ptr())
+    return d_out
+
+
 def sharded_verify(eng, n_bits, m, batch, scalars, points, group=None):
     """verdicts for `batch` proofs (numpy SoA arrays scalars[5,B,32], points[rows,B,64]); each rank
     verifies its contiguous slice and all ranks return all verdicts."""

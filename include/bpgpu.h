@@ -108,6 +108,11 @@ int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok)
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
 int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
 
+/* bp_point_sum_dev   d_out = sum of n affine points, device pointers, asynchronous on the context's stream: the fold
+ *                   of `<>` over a list (the right-nested sum of Utils.hs:78-80 without the scalars).  Combines the
+ *                   per-GPU partial sums of a sumExps whose point range is sharded over GPUs. */
+int bp_point_sum_dev(bp_ctx* ctx, const void* d_points, size_t n, void* d_out);
+
 /* bp_msm_dev_static  bp_msm_dev for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  *                   harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
  *                   same result bytes, asynchronous on the context's stream; it calls no hipMalloc, hipFree or

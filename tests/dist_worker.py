@@ -40,9 +40,19 @@ class OracleEngine:
 
 
 def main():
-    dist.init_process_group("gloo")
+    real = os.environ.get("BP_DIST_ENGINE") == "real"
+    if real:  # -m gpu: the same worker over the real engine and RCCL (backend "nccl")
+        import torch
+        from bulletproofs_amd import Engine
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        eng = Engine(local)
+        eng.set_generators(o.gs(2), o.hs(2), o.h())
+    else:
+        dist.init_process_group("gloo")
+        eng = OracleEngine()
     rank, world = dist.get_rank(), dist.get_world_size()
-    eng = OracleEngine()
     rng = random.Random(5)  # same data on every rank
     # --- MSM sharded over point ranges ---
     n = 11
@@ -51,6 +61,24 @@ def main():
     got = _lib.dec_point(bpdist.sharded_msm(eng, _lib.enc_scalars(es), _lib.enc_points(ps), n))
     assert got == o.sum_exps(es, ps), "sharded MSM mismatch on rank %d" % rank
     assert bpdist.shard_range(11, 0, 2) == (0, 6) and bpdist.shard_range(11, 1, 2) == (6, 11)
+    if real:  # the device-resident form: shards stay in HBM, partial sums are all-gathered on the device
+        import torch
+        lo, hi = bpdist.shard_range(n, rank, world)
+        d_s = torch.frombuffer(bytearray(_lib.enc_scalars(es[lo:hi])), dtype=torch.uint8).cuda()
+        d_p = torch.frombuffer(bytearray(_lib.enc_points(ps[lo:hi])), dtype=torch.uint8).cuda()
+        d_o = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        bpdist.sharded_msm_dev(eng, d_s, d_p, hi - lo, d_o)
+        eng.sync()
+        assert _lib.dec_point(bytes(d_o.cpu().numpy())) == o.sum_exps(es, ps), "device-resident sharded MSM mismatch"
+        # bp_point_sum_dev alone: the fold of <> over a list, incl. O and a pair P, -P
+        qs = ps[:5] + [o.O, o.point_neg(ps[0])]
+        d_q = torch.frombuffer(bytearray(_lib.enc_points(qs)), dtype=torch.uint8).cuda()
+        eng.point_sum_dev(d_q.data_ptr(), len(qs), d_o.data_ptr())
+        eng.sync()
+        exp = o.O
+        for q in qs:
+            exp = o.point_add(exp, q)
+        assert _lib.dec_point(bytes(d_o.cpu().numpy())) == exp
     # --- proofs sharded over ranks ---
     nb, B = 2, 5
     proofs, vcs = [], []
@@ -75,6 +103,8 @@ def main():
     assert v.tolist() == [1, 1, 1, 0, 1], "sharded verify mismatch on rank %d: %s" % (rank, v.tolist())
     dist.barrier()
     dist.destroy_process_group()
+    if real:
+        eng.close()
     print("rank %d ok" % rank)
 
 

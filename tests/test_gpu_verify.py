@@ -215,3 +215,71 @@ def test_host_layer_verify_batch(eng_gens):
         assert [b != 0 for b in job.run()] == exp
         assert [b != 0 for b in job.run()] == exp  # re-runnable
         job.close()
+
+
+def test_invalid_encodings_do_not_verify(eng_gens):
+    """Off-curve points make that proof (and only that proof) fail; O stays a legal point (padding commitments,
+    Verifier.hs:37-38, exercised by the m = 3 cases above).  Coordinates >= p and scalars >= r are refused by the same
+    kernel; honest 256-bit values leave no room to build such an encoding from a valid proof, so that arm is
+    covered by the generator test below (canonical check) only."""
+    b = golden()["bench_proof"]
+    pr, vc = load_proof(b["proof"]), up(b["vCommit"])
+    x, y = pr["t1Commit"]
+    off_curve = dict(pr, t1Commit=(x, (y + 1) % o.P))
+    ipp = dict(pr["productProof"])
+    ipp["lCommits"] = [(ipp["lCommits"][0][0], (ipp["lCommits"][0][1] + 5) % o.P)] + list(ipp["lCommits"][1:])
+    bad_l = dict(pr, productProof=ipp)
+    proofs = [pr, off_curve, bad_l, pr]
+    sc, pts, _ = pack_batch(proofs, [[vc]] * len(proofs), 1)
+    assert eng_gens.verify_batch(64, 1, len(proofs), sc, pts) == [True, False, False, True]
+    # an off-curve V fails only through the check (verifyTPoly would otherwise run on garbage)
+    sc, pts, _ = pack_batch([pr, pr], [[(vc[0], (vc[1] + 1) % o.P)], [vc]], 1)
+    assert eng_gens.verify_batch(64, 1, 2, sc, pts) == [False, True]
+
+
+def test_generators_are_validated_and_replacing_them_invalidates_batches(engine):
+    """bp_ctx_set_generators refuses points that are not finite curve points (and leaves the context without
+    generators, not with half a table); a batch object created before the generators were replaced is refused."""
+    gs, hs, h = o.gs(4), o.hs(4), o.h()
+    engine.set_generators(gs, hs, h)
+    vb = engine.vbatch(4, 1, 1)
+    bad = list(gs)
+    bad[2] = (bad[2][0], (bad[2][1] + 1) % o.P)
+    with pytest.raises(_lib.BpError):
+        engine.set_generators(bad, hs, h)
+    with pytest.raises(_lib.BpError):
+        engine.set_generators(gs, hs, None)          # h = O
+    with pytest.raises(_lib.BpError):
+        engine.vbatch(4, 1, 1)                       # no generators installed after the failed calls
+    engine.set_generators(gs, hs, h)
+    rng = random.Random(3)
+    v, g = 9, rng.randrange(1, R)
+    pr = o.mrp_generate_proof(2**4, [(v, g)], *o.draw_blinders(rng, 4))
+    sc, pts, _ = pack_batch([pr], [[o.commit(v, g)]], 1)
+    with pytest.raises(_lib.BpError):
+        vb.load(sc, pts)                             # created against the old generator set
+    vb.close()
+    assert engine.verify_batch(4, 1, 1, sc, pts) == [True]
+    engine.set_generators(o.gs(128), o.hs(128), o.h())  # restore for the other tests
+
+
+def test_verify_batch_job_cache(eng_gens):
+    """bp_rangeproof_verify_batch keeps its job on the context: same shape again (other proofs), another shape, the
+    first shape again - always the oracle's verdicts."""
+    rng = random.Random(91)
+
+    def make(n, count):
+        ps, vs = [], []
+        for i in range(count):
+            v, g = rng.randrange(2**n), rng.randrange(1, R)
+            p = o.mrp_generate_proof(2**n, [(v, g)], *o.draw_blinders(rng, n))
+            c = o.commit(v, g)
+            if i % 2:
+                p = dict(p, t=(p["t"] + 1) % R)
+            ps.append(p)
+            vs.append([c])
+        return ps, vs
+    for n, count in [(8, 3), (8, 3), (4, 2), (8, 3), (8, 5)]:
+        ps, vs = make(n, count)
+        sc, pts, _ = pack_batch(ps, vs, 1)
+        assert eng_gens.verify_batch(n, 1, count, sc, pts) == [i % 2 == 0 for i in range(count)]
