@@ -124,7 +124,7 @@ def cpu_baseline(sc, pts, n_bits, sample, gpu_verdicts):
 # ---- config 3: MSM ----------------------------------------------------------------------------------------------
 def msm_choose_c(n):
     """msm_core.h msm_choose_c."""
-    for lim, c in ((32, 4), (128, 5), (512, 7), (2048, 8), (8192, 10), (32768, 11), (131072, 13), (524288, 14)):
+    for lim, c in ((32, 4), (128, 5), (512, 7), (2048, 8), (8192, 10), (32768, 11), (131072, 13)):
         if n < lim:
             return c
     return 16
@@ -240,6 +240,21 @@ def msm_bench(eng, rank, world, dist, logns, iters):
                 dr = (time.perf_counter() - t0) / iters
                 row[kind]["resident_ms"] = dr * 1e3
                 row[kind]["resident_points_per_s"] = n / dr
+            if world == 1 and nl > 65536:
+                # the same sum over PREPARED points (bp_msm_points: shifted copies, no window doublings), scalars
+                # uploaded from pinned memory in chunks behind the recoding; result checked against the plain MSM's
+                ref = bytes(d_out.cpu().numpy())
+                mp = eng.msm_points(d_points=d_p.data_ptr(), n=nl)
+                if mp.run(h_s.data_ptr()) != ref:
+                    raise SystemExit("PARITY FAILURE: bp_msm_points_run differs from bp_msm_dev at N = 2^%d (%s)" % (logn, kind))
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    mp.run(h_s.data_ptr())
+                dp = (time.perf_counter() - t0) / iters
+                mp.close()
+                row[kind]["prepared_ms"] = dp * 1e3
+                row[kind]["prepared_points_per_s"] = n / dp
+                row[kind]["prepared_frac"] = mads / dp / 1e12 / PEAK_TMAD
         out.append(row)
     return out
 
@@ -481,6 +496,8 @@ def main():
                 "metric": "MSM points/sec (secp256k1, BASELINE.json configs[2])",
                 "n": top["n"], "points_per_s": top["uniform"]["points_per_s"], "ms": top["uniform"]["ms"],
                 "frac": top["uniform"]["frac"],
+                "prepared_points_per_s": top["uniform"].get("prepared_points_per_s"),
+                "prepared_frac": top["uniform"].get("prepared_frac"),
                 "what": "sum e_i P_i, points resident (one-time upload excluded), scalars uploaded from pinned host "
                         "memory every iteration (included), %d GPU(s) by contiguous point ranges + all-gather of "
                         "64-byte partial sums; frac = SURVEY 8d algorithmic mads / (time x %d x %.1f Tmad/s)"

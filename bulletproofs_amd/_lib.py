@@ -54,6 +54,11 @@ SYMBOLS = {
     "bp_point_on_curve": (_int, [_vp, _u8p, _sz, _u8p]),
     "bp_msm": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "bp_msm_points_create": (_int, [_vp, _u8p, _sz, ctypes.POINTER(_vp)]),
+    "bp_msm_points_create_dev": (_int, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
+    "bp_msm_points_destroy": (None, [_vp]),
+    "bp_msm_points_run": (_int, [_vp, _vp, _vp, _u8p]),
+    "bp_msm_points_run_dev": (_int, [_vp, _vp, _vp, _vp]),
     "bp_point_sum_dev": (_int, [_vp, _vp, _sz, _vp]),
     "bp_msm_dev_static": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_field_op": (_int, [_vp, _int, _int, _u8p, _u8p, _sz, _u8p]),
@@ -227,6 +232,10 @@ class Engine:
 
     def msm_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
         self._check(self.lib.bp_msm_dev(self.h, d_scalars, d_points, n, window_bits, d_out), "bp_msm_dev")
+
+    def msm_points(self, points=None, d_points=None, n=None):
+        """bp_msm_points_create(_dev): prepare a fixed point list (bytes, or a device pointer with n) once."""
+        return MsmPoints(self, points, d_points, n)
 
     def point_sum_dev(self, d_points, n, d_out):
         self._check(self.lib.bp_point_sum_dev(self.h, d_points, n, d_out), "bp_point_sum_dev")
@@ -533,6 +542,36 @@ def log_base2(upper_bound):
     lib = load_library()
     nbytes = max(1, (upper_bound.bit_length() + 7) // 8)
     return lib.bp_log_base2(upper_bound.to_bytes(nbytes, "little"), nbytes)
+
+
+class MsmPoints:
+    """bp_msm_points_*: `sumExps es ps` for a point list that stays the same call after call."""
+
+    def __init__(self, eng, points, d_points, n):
+        self.eng = eng
+        h = ctypes.c_void_p()
+        if points is not None:
+            n = len(points) // 64
+            rc = eng.lib.bp_msm_points_create(eng.h, points, n, ctypes.byref(h))
+        else:
+            rc = eng.lib.bp_msm_points_create_dev(eng.h, d_points, n, ctypes.byref(h))
+        eng._check(rc, "bp_msm_points_create")
+        self.h, self.n = h, n
+
+    def run(self, scalars):
+        """scalars: bytes (n x 32) or an int host address (e.g. of pinned memory) -> 64 result bytes."""
+        out = ctypes.create_string_buffer(64)
+        ptr = scalars if isinstance(scalars, int) else ctypes.cast(ctypes.c_char_p(scalars), ctypes.c_void_p)
+        self.eng._check(self.eng.lib.bp_msm_points_run(self.eng.h, self.h, ptr, out), "bp_msm_points_run")
+        return out.raw
+
+    def run_dev(self, d_scalars, d_out):
+        self.eng._check(self.eng.lib.bp_msm_points_run_dev(self.eng.h, self.h, d_scalars, d_out), "bp_msm_points_run_dev")
+
+    def close(self):
+        if self.h:
+            self.eng.lib.bp_msm_points_destroy(self.h)
+            self.h = None
 
 
 class VJob:

@@ -119,6 +119,11 @@ int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, 
 int msm_static_init(int device);
 size_t msm_static_bytes();
 int msm_run_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out);
+// A fixed point set prepared once for many MSMs (bp_msm_points_*): shifted copies 2^(c w) P_i, own workspace.
+struct MsmPoints;
+int msm_points_create(bp_ctx* ctx, const uint8_t* h_points, const void* d_points, size_t n, MsmPoints** out);
+void msm_points_destroy(MsmPoints* mp);
+int msm_points_run(MsmPoints* mp, const void* d_scalars, const uint8_t* h_scalars, void* d_out, uint8_t* h_out);
 // ipp.hip (device pointers, asynchronous on ctx->stream)
 // One batch of two-scalar linear combinations: out[i] = ka*a[i] + kb*b[i] (+ c[i] when c != null), i < n.
 // sa / sb, when non-null, give per-lane canonical scalars (32 B each) instead of the shared ka / kb.

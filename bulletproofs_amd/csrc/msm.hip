@@ -15,6 +15,7 @@
 //   7 k_window_sum    workgroup tree reduction of the segment values of one window
 //   8 k_final         Horner over the windows + affine normalisation
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include "engine.h"
 #include "devio.h"
@@ -46,11 +47,12 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scal
 // GLV form (glv.h): scalar i becomes the two 129-bit half-scalars k1, k2 with k = k1 + k2*lambda; entry 2i is
 // k1 on P_i, entry 2i + 1 is k2 on phi(P_i) = (beta x, y).  Half the windows, hence half the buckets to
 // reduce and half the doublings in the final Horner chain; a half-scalar's sign flips the entry's sign flag.
-__global__ void __launch_bounds__(256) k_recode_glv(const uint8_t* __restrict__ scalars, uint32_t n, MsmPlan pl,
-                                                   uint32_t* __restrict__ codes, uint32_t* __restrict__ ranks,
+// Scalars [i0, i1) of n (a chunk: the host-scalar entry point recodes chunk by chunk behind the upload).
+__global__ void __launch_bounds__(256) k_recode_glv(const uint8_t* __restrict__ scalars, uint32_t n, uint32_t i0, uint32_t i1,
+                                                   MsmPlan pl, uint32_t* __restrict__ codes, uint32_t* __restrict__ ranks,
                                                    uint32_t* __restrict__ hist) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  uint32_t i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i1) return;
   u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)i * 32));
   GlvHalf h[2];
   glv_split(k, h[0], h[1]);
@@ -69,7 +71,23 @@ __global__ void __launch_bounds__(256) k_recode_glv(const uint8_t* __restrict__ 
       if (code != MSM_SKIP) code ^= flip;
       codes[(size_t)w * ne + j] = code;
       if (w == pl.W - 1 && top_bits <= 5) break;  // handled below, wave-aggregated
-      if (code != MSM_SKIP) ranks[(size_t)w * ne + j] = atomicAdd(&hist[(size_t)w * pl.nb + (code & ~MSM_NEG)], 1u);
+      // Structured scalars pile onto bucket 0 (digit +-1): {0,1} scalars in window 0, the carry digit behind the top of
+      // 64-bit scalars, small scalars in general.  A million returning atomics on ONE address serialise (measured:
+      // 2^20 {0,1} scalars 7.2 ms against 4.9 ms uniform), so the lanes of a wave that hit bucket 0 share one atomic.
+      const bool valid = code != MSM_SKIP;
+      const uint32_t bucket = code & ~MSM_NEG;
+      const bool hot = valid && bucket == 0u;
+      const unsigned long long hm = __ballot(hot);
+      if (hot) {
+        const int leader = __ffsll((long long)hm) - 1;
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&hist[(size_t)w * pl.nb], (uint32_t)__popcll(hm));
+        base = __shfl(base, leader, 64);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+        ranks[(size_t)w * ne + j] = base + below;
+      } else if (valid) {
+        ranks[(size_t)w * ne + j] = atomicAdd(&hist[(size_t)w * pl.nb + bucket], 1u);
+      }
     }
   }
 }
@@ -104,11 +122,160 @@ __device__ __forceinline__ affine entry_point(const uint8_t* __restrict__ points
   return p;
 }
 
+// ---- two-level bucket sort ------------------------------------------------------------------------------------
+// The one-level ranking above spends one device-scope returning atomic per entry (19 M at N = 2^20: 1.1 ms, two thirds
+// of it waiting).  Here the entries of a window are first partitioned by the HIGH bits of their bucket into coarse
+// bins of 2^FINE_BITS buckets (histogram and placement through LDS counters of a 1024-thread workgroup; one global
+// atomic per workgroup and bin), then one workgroup per coarse bin counting-sorts its entries by the low bucket bits
+// entirely in LDS and emits the per-bucket counts and offsets the accumulation kernels read.
+constexpr int FINE_BITS = 7, FINE = 1 << FINE_BITS;
+constexpr int CO_MAXCNT = 17 * 256;   // (window, coarse bin) counters: W <= 17 for c >= 8, nb / 128 <= 256
+constexpr int CO_SCALARS = 4096;      // scalars per workgroup of k_recode_coarse (8,192 half-scalar entries per window)
+constexpr int CO_TILE = 8192;         // entries per window and workgroup of k_scatter_coarse
+
+__global__ void __launch_bounds__(1024) k_recode_coarse(const uint8_t* __restrict__ scalars, uint32_t n, uint32_t i0, uint32_t i1,
+                                                       MsmPlan pl, int wc, int nbin, uint32_t* __restrict__ codes,
+                                                       uint32_t* __restrict__ chist) {
+  __shared__ uint32_t lh[CO_MAXCNT];
+  const int ncnt = wc * nbin;
+  for (int k = threadIdx.x; k < ncnt; k += 1024) lh[k] = 0;
+  __syncthreads();
+  const size_t ne = (size_t)2 * n;
+  for (int sidx = 0; sidx < CO_SCALARS / 1024; sidx++) {
+    const uint32_t i = i0 + blockIdx.x * CO_SCALARS + sidx * 1024 + threadIdx.x;
+    if (i < i1) {
+      u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)i * 32));
+      GlvHalf h[2];
+      glv_split(k, h[0], h[1]);
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        u256 sv = u256_zero();
+#pragma unroll
+        for (int q = 0; q < 5; q++) sv.v[q] = h[hh].m[q];
+        const uint32_t flip = h[hh].neg ? MSM_NEG : 0u;
+        const size_t j = (size_t)2 * i + hh;
+        uint32_t carry = 0;
+        for (int w = 0; w < pl.W; w++) {
+          uint32_t code = recode_next(sv, pl.c, carry);
+          if (code != MSM_SKIP) code ^= flip;
+          codes[(size_t)w * ne + j] = code;
+          if (w < wc && code != MSM_SKIP) atomicAdd(&lh[w * nbin + (int)((code & ~MSM_NEG) >> FINE_BITS)], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncnt; k += 1024)
+    if (lh[k]) atomicAdd(&chist[k], lh[k]);
+}
+
+// cstart = exclusive scan of chist over the cnt (window, bin) counters; ccur = cstart
+__global__ void __launch_bounds__(1024) k_coarse_scan(const uint32_t* __restrict__ chist, uint32_t cnt,
+                                                     uint32_t* __restrict__ cstart, uint32_t* __restrict__ ccur) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const uint32_t per = (cnt + 1023) / 1024;
+  uint32_t sum = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    uint32_t b = t * per + k;
+    if (b < cnt) sum += chist[b];
+  }
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;
+  for (uint32_t k = 0; k < per; k++) {
+    uint32_t b = t * per + k;
+    if (b < cnt) {
+      cstart[b] = run;
+      ccur[b] = run;
+      run += chist[b];
+    }
+  }
+}
+
+// coarse[pos] = entry index (24 bits) | low bucket bits << 24 | sign, grouped by (window, coarse bin)
+__global__ void __launch_bounds__(1024) k_scatter_coarse(const uint32_t* __restrict__ codes, uint32_t ne, MsmPlan pl, int wc,
+                                                        int nbin, uint32_t* __restrict__ ccur, uint32_t* __restrict__ coarse) {
+  __shared__ uint32_t lcnt[CO_MAXCNT], lbase[CO_MAXCNT];
+  const int ncnt = wc * nbin;
+  for (int k = threadIdx.x; k < ncnt; k += 1024) lcnt[k] = 0;
+  __syncthreads();
+  const uint32_t j0 = blockIdx.x * CO_TILE;
+  for (int w = 0; w < wc; w++)
+    for (int sidx = 0; sidx < CO_TILE / 1024; sidx++) {
+      const uint32_t j = j0 + sidx * 1024 + threadIdx.x;
+      if (j < ne) {
+        const uint32_t code = codes[(size_t)w * ne + j];
+        if (code != MSM_SKIP) atomicAdd(&lcnt[w * nbin + (int)((code & ~MSM_NEG) >> FINE_BITS)], 1u);
+      }
+    }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncnt; k += 1024) {
+    const uint32_t c = lcnt[k];
+    lbase[k] = c ? atomicAdd(&ccur[k], c) : 0u;
+    lcnt[k] = 0;
+  }
+  __syncthreads();
+  for (int w = 0; w < wc; w++)
+    for (int sidx = 0; sidx < CO_TILE / 1024; sidx++) {
+      const uint32_t j = j0 + sidx * 1024 + threadIdx.x;
+      if (j < ne) {
+        const uint32_t code = codes[(size_t)w * ne + j];
+        if (code != MSM_SKIP) {
+          const uint32_t bucket = code & ~MSM_NEG;
+          const int k = w * nbin + (int)(bucket >> FINE_BITS);
+          const uint32_t pos = lbase[k] + atomicAdd(&lcnt[k], 1u);
+          coarse[pos] = j | ((bucket & (FINE - 1)) << 24) | (code & MSM_NEG);
+        }
+      }
+    }
+}
+
+// One workgroup per (window, coarse bin): counting sort by the low bucket bits in LDS.  Writes, for each of the
+// bin's FINE buckets, hist (count) and offs (start in `sorted`), and the entries (index | sign) grouped by bucket.
+__global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ cstart,
+                                                  const uint32_t* __restrict__ chist, MsmPlan pl, int nbin,
+                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                  uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cnt[FINE], cur[FINE];
+  const int k = blockIdx.x, w = k / nbin, b = k % nbin;
+  const uint32_t s0 = cstart[k], s1 = s0 + chist[k];
+  if (threadIdx.x < FINE) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t p = s0 + threadIdx.x; p < s1; p += 256) atomicAdd(&cnt[(coarse[p] >> 24) & (FINE - 1)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = s0;
+    for (int q = 0; q < FINE; q++) {
+      cur[q] = run;
+      run += cnt[q];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < FINE) {
+    const size_t bid = (size_t)w * pl.nb + (size_t)b * FINE + threadIdx.x;
+    hist[bid] = cnt[threadIdx.x];
+    offs[bid] = cur[threadIdx.x];
+  }
+  __syncthreads();
+  for (uint32_t p = s0 + threadIdx.x; p < s1; p += 256) {
+    const uint32_t v = coarse[p];
+    const uint32_t pos = atomicAdd(&cur[(v >> 24) & (FINE - 1)], 1u);
+    if (pos < s1) sorted[pos] = (v & 0x00FFFFFFu) | (v & MSM_NEG);
+  }
+}
+
 // ---- 2. per-window exclusive scan (one workgroup of 1024 per window) -----------
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t n, MsmPlan pl,
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t n, MsmPlan pl, int w0,
                                               uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
   __shared__ uint32_t part[1024];
-  int w = blockIdx.x, t = threadIdx.x;
+  int w = w0 + blockIdx.x, t = threadIdx.x;
   int per = (pl.nb + 1023) / 1024;
   const uint32_t* h = hist + (size_t)w * pl.nb;
   uint32_t sum = 0;
@@ -137,10 +304,10 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
 
 // ---- 3. scatter ------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ ranks,
-                                                uint32_t n, MsmPlan pl, const uint32_t* __restrict__ offs,
+                                                uint32_t n, MsmPlan pl, int w0, const uint32_t* __restrict__ offs,
                                                 uint32_t* __restrict__ sorted) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  int w = blockIdx.y;
+  int w = w0 + blockIdx.y;
   if (i >= n) return;
   uint32_t code = codes[(size_t)w * n + i];
   if (code == MSM_SKIP) return;
@@ -194,14 +361,16 @@ __global__ void __launch_bounds__(1024) k_cls_scatter(const uint32_t* __restrict
 }
 
 // ---- 5a. light buckets: one lane per bucket ----------------------------------------
+// shift_stride != 0: `points` holds, for window w, the copies 2^(c w) P_i at points + w * shift_stride (bp_msm_points)
 __global__ void __launch_bounds__(256) k_light(const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
                                               const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
                                               const uint32_t* __restrict__ order, uint32_t total, uint32_t glv,
-                                              xyzz* __restrict__ buckets) {
+                                              uint32_t nb, size_t shift_stride, xyzz* __restrict__ buckets) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t bid = order[t];
   uint32_t cnt = hist[bid];
+  points += (size_t)(bid / nb) * shift_stride;
   if (cnt > (uint32_t)LIGHT_MAX) return;  // heavy path owns it
   xyzz acc = xyzz_inf();
   if (cnt) {
@@ -260,7 +429,7 @@ __global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict_
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ bins,
                                                      const uint32_t* __restrict__ heavy_off, uint32_t glv,
-                                                     xyzz* __restrict__ partial) {
+                                                     uint32_t nb, size_t shift_stride, xyzz* __restrict__ partial) {
   __shared__ xyzz lds[4];
   uint32_t nheavy = bins[2 * NBINS];
   if (nheavy == 0) return;
@@ -277,10 +446,11 @@ __global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict_
     uint32_t s0 = (j - heavy_off[lo]) * SLICE;
     uint32_t s1 = s0 + SLICE < cnt ? s0 + SLICE : cnt;
     const uint32_t* lst = sorted + offs[bid];
+    const uint8_t* wpoints = points + (size_t)(bid / nb) * shift_stride;
     xyzz acc = xyzz_inf();
     for (uint32_t k = s0 + threadIdx.x; k < s1; k += blockDim.x) {
       uint32_t e = lst[k];
-      affine p = entry_point(points, e, glv);
+      affine p = entry_point(wpoints, e, glv);
       bucket_add(acc, p, (e & MSM_NEG) != 0);
     }
     acc = block_sum(acc, lds);
@@ -300,6 +470,49 @@ __global__ void __launch_bounds__(64) k_heavy_final(const uint32_t* __restrict__
     for (uint32_t k = a + threadIdx.x; k < b; k += 64) acc = xyzz_add(acc, ld_xyzz(&partial[k]));
     acc = wave_sum(acc);
     if (threadIdx.x == 0) st_xyzz(&buckets[order[h]], acc);
+  }
+}
+
+// ---- 5c. prepared points: all windows carry weight 1, so their buckets add up index by index ----------------
+// buckets[b] += sum_{w >= 1} buckets[w * nb + b]
+__global__ void __launch_bounds__(256) k_combine_windows(xyzz* __restrict__ buckets, uint32_t W, uint32_t nb) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  xyzz acc = ld_xyzz(&buckets[b]);
+  for (uint32_t w = 1; w < W; w++) acc = xyzz_add(acc, ld_xyzz(&buckets[(size_t)w * nb + b]));
+  st_xyzz(&buckets[b], acc);
+}
+
+// out[w][i] = 2^(c w) * P_i, affine, for w < W: c doublings between copies, then ONE inversion per point for all its
+// copies (Montgomery's trick with the prefix products parked in the output slots).  scratch: [W][n] XYZZ.
+__global__ void __launch_bounds__(256) k_msm_shift(const uint8_t* __restrict__ points, uint32_t n, int c, int W,
+                                                  xyzz* __restrict__ scratch, uint8_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  xyzz cur = xyzz_from_affine(ld_affine(points + (size_t)i * 64));
+  for (int w = 0; w < W; w++) {
+    st_xyzz(&scratch[(size_t)w * n + i], cur);
+    if (w + 1 < W)
+      for (int k = 0; k < c; k++) cur = xyzz_dbl(cur);
+  }
+  u256 run = u256_one();
+  for (int w = 0; w < W; w++) {
+    uint8_t* slot = out + ((size_t)w * n + i) * 64;
+    st_u256(slot, run);  // product of the earlier copies' ZZZ
+    u256 zzz = ld_u256(&scratch[(size_t)w * n + i].ZZZ);
+    if (!fq_is_zero(zzz)) run = fq_mul(run, zzz);  // the identity (and anything that doubled into it) stays out
+  }
+  u256 inv = fq_inv(run);
+  for (int w = W - 1; w >= 0; w--) {
+    uint8_t* slot = out + ((size_t)w * n + i) * 64;
+    xyzz e = ld_xyzz(&scratch[(size_t)w * n + i]);
+    if (fq_is_zero(e.ZZZ)) {
+      st_affine(slot, affine_inf());
+      continue;
+    }
+    u256 zi = fq_mul(inv, ld_u256(slot));  // 1 / ZZZ_w
+    inv = fq_mul(inv, e.ZZZ);
+    st_affine(slot, xyzz_to_affine_with_inv(e, zi));
   }
 }
 
@@ -461,8 +674,22 @@ static int msm_ws_get(bp_ctx* ctx, const MsmWsSource& src, size_t need, void** o
   return BP_OK;
 }
 
+// Prepared points (bp_msm_points): window w reads the copies 2^(c w) P_i at d_shifted + w * stride, so every window's
+// buckets carry weight 1 and the Horner chain over the windows (128 doublings in one wave) disappears.  h_scalars,
+// when set, are uploaded in `nchunks` pieces on copy_stream into d_stage, each piece recoded as soon as it has landed.
+struct MsmPrep {
+  const uint8_t* d_shifted;
+  size_t stride;
+  int c;
+  const uint8_t* h_scalars;
+  uint8_t* d_stage;
+  hipStream_t copy_stream;
+  hipEvent_t* ev;
+  int nchunks;
+};
+
 static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalars, const void* d_points, size_t n,
-                      int c_override, void* d_out_affine, void* d_out_xyzz) {
+                      int c_override, void* d_out_affine, void* d_out_xyzz, const MsmPrep* prep = nullptr) {
   hipStream_t st = ctx->stream;
   const bool profile = ctx->profile && !wsrc.fixed;  // event creation allocates: never on the static path
   void* ws = nullptr;
@@ -476,7 +703,7 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     ctx->err = "bp_msm: n must be below 2^27";
     return BP_ERR_ARG;
   }
-  if (c_override <= 0 && n <= msm_direct_max()) {
+  if (!prep && c_override <= 0 && n <= msm_direct_max()) {
     uint32_t nblk = (uint32_t)((n + 255) / 256);
     if ((rc = msm_ws_get(ctx, wsrc, (size_t)nblk * sizeof(xyzz), &ws)) != BP_OK) return rc;
     xyzz* partial = (xyzz*)ws;
@@ -488,12 +715,15 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     BP_TRY(hipGetLastError());
     return BP_OK;
   }
-  int c = c_override > 0 ? c_override : msm_choose_c(n);
+  int c = prep ? prep->c : (c_override > 0 ? c_override : msm_choose_c(n));
   if (c < 1 || c > 16) {
     ctx->err = "bp_msm: window_bits must be in 1..16";
     return BP_ERR_ARG;
   }
-  static const uint32_t glv = getenv("BP_MSM_NO_GLV") ? 0u : 1u;
+  static const uint32_t glv_env = getenv("BP_MSM_NO_GLV") ? 0u : 1u;
+  const uint32_t glv = prep ? 1u : glv_env;
+  const size_t shift_stride = prep ? prep->stride : 0;
+  if (prep) d_points = prep->d_shifted;
   MsmPlan pl = msm_plan(c, glv ? GLV_BITS : 256);
   const size_t ne = glv ? 2 * n : n;  // sorted entries per window
   size_t wn = (size_t)pl.W * ne;
@@ -506,13 +736,16 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   size_t max_slices = wn / SLICE + max_heavy + 1;
 
   // workspace layout (sizes computed with a null base first)
-  uint32_t *codes, *ranks, *sorted, *hist, *offs, *cursor, *order, *bins, *heavy_off;
+  uint32_t *codes, *ranks, *sorted, *hist, *offs, *cursor, *order, *bins, *heavy_off, *chist, *cstart, *ccur;
   xyzz *partial, *buckets, *segv, *wsum;
   auto carve = [&](void* base) {
     Carver cv(base);
     hist = cv.take<uint32_t>(nbt);          // zeroed each call
     bins = cv.take<uint32_t>(2 * NBINS + 8); // zeroed each call (contiguous with hist)
+    chist = cv.take<uint32_t>(CO_MAXCNT);    // zeroed each call: coarse-bin histogram of the two-level sort
     size_t zero_end = cv.off;
+    cstart = cv.take<uint32_t>(CO_MAXCNT);
+    ccur = cv.take<uint32_t>(CO_MAXCNT);
     codes = cv.take<uint32_t>(wn);
     ranks = cv.take<uint32_t>(wn);
     sorted = cv.take<uint32_t>(wn);
@@ -530,12 +763,40 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   size_t need = carve(nullptr);
   if ((rc = msm_ws_get(ctx, wsrc, need, &ws)) != BP_OK) return rc;
   carve(ws);
-  size_t zero_bytes = (size_t)((char*)(bins + 2 * NBINS + 8) - (char*)hist);
+  size_t zero_bytes = (size_t)((char*)(chist + CO_MAXCNT) - (char*)hist);
+  // Two-level bucket sort (GLV form, windows of at least FINE_BITS + 1 bits, entry indices below 2^24): the narrow top
+  // window, if any, keeps the LDS-ranked path of k_rank_top.  BP_MSM_SORT=atomic selects the one-level atomic ranking.
+  static const bool sort_atomic = getenv("BP_MSM_SORT") && !strcmp(getenv("BP_MSM_SORT"), "atomic");
+  const bool top_narrow = glv && GLV_BITS + 1 - pl.c * (pl.W - 1) <= 5;
+  const int wc = top_narrow ? pl.W - 1 : pl.W;
+  const int nbin = pl.nb >> FINE_BITS;
+  const bool two_level = glv && !sort_atomic && pl.c > FINE_BITS + 1 && ne < (1u << 24) && wc >= 1 && wc * nbin <= CO_MAXCNT;
   BP_TRY(hipMemsetAsync(hist, 0, zero_bytes, st));
 
   uint32_t n32 = (uint32_t)n, ne32 = (uint32_t)ne, nbt32 = (uint32_t)nbt;
-  if (glv)
-    hipLaunchKernelGGL(k_recode_glv, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl,
+  if (prep && prep->h_scalars) {
+    // upload and recode chunk by chunk: the copy engine moves chunk i + 1 while the recode kernel digests chunk i
+    const int nch = prep->nchunks < 1 ? 1 : prep->nchunks;
+    const uint32_t per = (uint32_t)(((n + nch - 1) / nch + 255) / 256 * 256);
+    int ci = 0;
+    for (uint32_t i0 = 0; i0 < n32; i0 += per, ci++) {
+      const uint32_t i1 = i0 + per < n32 ? i0 + per : n32;
+      BP_TRY(hipMemcpyAsync(prep->d_stage + (size_t)i0 * 32, prep->h_scalars + (size_t)i0 * 32, (size_t)(i1 - i0) * 32,
+                            hipMemcpyHostToDevice, prep->copy_stream));
+      BP_TRY(hipEventRecord(prep->ev[ci], prep->copy_stream));
+      BP_TRY(hipStreamWaitEvent(st, prep->ev[ci], 0));
+      if (two_level)
+        hipLaunchKernelGGL(k_recode_coarse, dim3((i1 - i0 + CO_SCALARS - 1) / CO_SCALARS), dim3(1024), 0, st,
+                           (const uint8_t*)prep->d_stage, n32, i0, i1, pl, wc, nbin, codes, chist);
+      else
+        hipLaunchKernelGGL(k_recode_glv, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, (const uint8_t*)prep->d_stage, n32, i0,
+                           i1, pl, codes, ranks, hist);
+    }
+  } else if (two_level)
+    hipLaunchKernelGGL(k_recode_coarse, dim3((n32 + CO_SCALARS - 1) / CO_SCALARS), dim3(1024), 0, st, (const uint8_t*)d_scalars,
+                       n32, 0u, n32, pl, wc, nbin, codes, chist);
+  else if (glv)
+    hipLaunchKernelGGL(k_recode_glv, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, 0u, n32, pl,
                        codes, ranks, hist);
   if (glv && GLV_BITS + 1 - pl.c * (pl.W - 1) <= 5)
     hipLaunchKernelGGL(k_rank_top, dim3((ne32 + 255) / 256), dim3(256), 0, st, ne32, pl, codes, ranks, hist);
@@ -543,8 +804,21 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   } else
     hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl, codes,
                        ranks, hist);
-  hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, ne32, pl, offs, cursor);
-  hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W), dim3(256), 0, st, codes, ranks, ne32, pl, offs, sorted);
+  if (two_level) {
+    // windows [0, wc): coarse partition by the high bucket bits, then one workgroup per coarse bin sorts it in LDS
+    hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, chist, (uint32_t)(wc * nbin), cstart, ccur);
+    hipLaunchKernelGGL(k_scatter_coarse, dim3((ne32 + CO_TILE - 1) / CO_TILE), dim3(1024), 0, st, codes, ne32, pl, wc, nbin,
+                       ccur, ranks /* coarse entries */);
+    hipLaunchKernelGGL(k_sort_fine, dim3(wc * nbin), dim3(256), 0, st, ranks, cstart, chist, pl, nbin, hist, offs, sorted);
+    if (wc < pl.W) {  // the narrow top window: ranks from k_rank_top, one scan and scatter for it alone
+      hipLaunchKernelGGL(k_scan, dim3(pl.W - wc), dim3(1024), 0, st, hist, ne32, pl, wc, offs, cursor);
+      hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W - wc), dim3(256), 0, st, codes, ranks, ne32, pl, wc, offs,
+                         sorted);
+    }
+  } else {
+    hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, ne32, pl, 0, offs, cursor);
+    hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W), dim3(256), 0, st, codes, ranks, ne32, pl, 0, offs, sorted);
+  }
   hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
   hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
   hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
@@ -563,7 +837,7 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
   }
   hipLaunchKernelGGL(k_light, dim3((nbt32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs,
-                     sorted, order, nbt32, glv, buckets);
+                     sorted, order, nbt32, glv, (uint32_t)pl.nb, shift_stride, buckets);
   if (profile) {
     BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
     ctx->prof_pending_light = true;
@@ -572,9 +846,13 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
   uint32_t hgrid = (uint32_t)(max_slices < 4096 ? max_slices : 4096);
   hipLaunchKernelGGL(k_heavy_slices, dim3(hgrid), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,
-                     order, bins, heavy_off, glv, partial);
+                     order, bins, heavy_off, glv, (uint32_t)pl.nb, shift_stride, partial);
   uint32_t fgrid = (uint32_t)(max_heavy < 4096 ? max_heavy : 4096);
   hipLaunchKernelGGL(k_heavy_final, dim3(fgrid), dim3(64), 0, st, order, bins, heavy_off, partial, buckets);
+  if (prep) {  // all windows weigh 1: add their buckets index by index, then reduce ONE window; no Horner chain
+    hipLaunchKernelGGL(k_combine_windows, dim3((pl.nb + 255) / 256), dim3(256), 0, st, buckets, (uint32_t)pl.W, (uint32_t)pl.nb);
+    pl.W = 1;
+  }
   uint32_t nsegt = (uint32_t)pl.W * pl.nseg;
   hipLaunchKernelGGL(k_seg_reduce, dim3((nsegt + 255) / 256), dim3(256), 0, st, buckets, pl, segv);
   hipLaunchKernelGGL(k_window_sum, dim3(pl.W), dim3(256), 0, st, segv, pl, wsum);
@@ -622,6 +900,131 @@ int msm_run_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, siz
     return BP_ERR_STATE;
   }
   return msm_run_ws(ctx, MsmWsSource{ptr, MSM_STATIC_BYTES}, d_scalars, d_points, n, c_override, d_out, nullptr);
+}
+
+// ---- bp_msm_points: a fixed point set prepared once (include/bpgpu.h) ---------------------------------------------
+struct MsmPoints {
+  bp_ctx* ctx;
+  size_t n;
+  int c, W;
+  DevBuf shifted;   // [W][n] affine copies 2^(c w) P_i
+  DevBuf ws;        // the bucket method's workspace for this n (sized once)
+  DevBuf stage;     // n scalars uploaded from the host
+  hipStream_t copy_stream;
+  hipEvent_t ev[8];
+  hipEvent_t ev_start;  // orders a new upload behind the previous call's readers of the staging buffer
+  uint8_t* d_out;   // 64 B result slot
+};
+
+int msm_points_create(bp_ctx* ctx, const uint8_t* h_points, const void* d_points, size_t n, MsmPoints** out) {
+  *out = nullptr;
+  if (n < 1 || n >= (1ull << 24)) {
+    ctx->err = "bp_msm_points_create: n must be in 1..2^24";
+    return BP_ERR_ARG;
+  }
+  MsmPoints* mp = new MsmPoints();
+  mp->ctx = ctx;
+  mp->n = n;
+  mp->c = msm_choose_c(n);
+  MsmPlan pl = msm_plan(mp->c, GLV_BITS);
+  mp->W = pl.W;
+  mp->copy_stream = nullptr;
+  for (auto& e : mp->ev) e = nullptr;
+  mp->ev_start = nullptr;
+  auto fail = [&](int rc, const char* msg) {
+    ctx->err = msg;
+    mp->shifted.release();
+    mp->ws.release();
+    mp->stage.release();
+    for (auto& e : mp->ev)
+      if (e) (void)hipEventDestroy(e);
+    if (mp->ev_start) (void)hipEventDestroy(mp->ev_start);
+    if (mp->copy_stream) (void)hipStreamDestroy(mp->copy_stream);
+    delete mp;
+    return rc;
+  };
+  const size_t copies = (size_t)pl.W * n;
+  if (mp->shifted.reserve(copies * 64) != 0 || mp->stage.reserve(n * 32 + 256) != 0)
+    return fail(BP_ERR_NOMEM, "bp_msm_points_create: allocation failed");
+  DevBuf tmp;  // XYZZ scratch of the shift kernel (+ the uploaded points)
+  if (tmp.reserve(copies * sizeof(xyzz) + n * 64) != 0) return fail(BP_ERR_NOMEM, "bp_msm_points_create: scratch allocation failed");
+  hipStream_t st = ctx->stream;
+  uint8_t* d_in = (uint8_t*)tmp.p + copies * sizeof(xyzz);
+  hipError_t e = hipMemcpyAsync(d_in, h_points ? (const void*)h_points : d_points, n * 64,
+                                h_points ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_msm_shift, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, (uint32_t)n, mp->c, mp->W,
+                       (xyzz*)tmp.p, (uint8_t*)mp->shifted.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  tmp.release();
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&mp->copy_stream, hipStreamNonBlocking);
+  for (auto& ev : mp->ev)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&mp->ev_start, hipEventDisableTiming);
+  if (e != hipSuccess) return fail(BP_ERR_DEVICE, "bp_msm_points_create: device error while preparing the points");
+  mp->d_out = (uint8_t*)mp->stage.p + n * 32;
+  *out = mp;
+  return BP_OK;
+}
+
+void msm_points_destroy(MsmPoints* mp) {
+  if (!mp) return;
+  (void)hipSetDevice(mp->ctx->device);
+  (void)hipStreamSynchronize(mp->ctx->stream);
+  (void)hipStreamSynchronize(mp->copy_stream);
+  mp->shifted.release();
+  mp->ws.release();
+  mp->stage.release();
+  for (auto& e : mp->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (mp->ev_start) (void)hipEventDestroy(mp->ev_start);
+  (void)hipStreamDestroy(mp->copy_stream);
+  delete mp;
+}
+
+// d_scalars (device) or h_scalars (host; pinned memory overlaps the upload with the recoding); result to d_out (device)
+// and/or h_out (host, synchronous).
+int msm_points_run(MsmPoints* mp, const void* d_scalars, const uint8_t* h_scalars, void* d_out, uint8_t* h_out) {
+  bp_ctx* ctx = mp->ctx;
+  MsmPrep pr;
+  pr.d_shifted = (const uint8_t*)mp->shifted.p;
+  pr.stride = mp->n * 64;
+  pr.c = mp->c;
+  pr.h_scalars = h_scalars;
+  pr.d_stage = (uint8_t*)mp->stage.p;
+  pr.copy_stream = mp->copy_stream;
+  pr.ev = mp->ev;
+  static const int env_chunks = [] {
+    const char* e = getenv("BP_MSM_UPLOAD_CHUNKS");
+    int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 8 ? v : 0;
+  }();
+  pr.nchunks = env_chunks ? env_chunks : (mp->n >= (1u << 17) ? 8 : 1);
+  if (h_scalars) {  // the previous call's recode kernels may still read the staging buffer
+    BP_TRY(hipEventRecord(mp->ev_start, ctx->stream));
+    BP_TRY(hipStreamWaitEvent(mp->copy_stream, mp->ev_start, 0));
+  }
+  // the handle owns its workspace: grow-only, sized by the first call
+  struct Own {
+    bp_ctx* ctx;
+    DevBuf saved;
+    DevBuf& mine;
+    Own(bp_ctx* c, DevBuf& m) : ctx(c), saved(c->msm_ws), mine(m) { ctx->msm_ws = mine; }
+    ~Own() {
+      mine = ctx->msm_ws;
+      ctx->msm_ws = saved;
+    }
+  } own(ctx, mp->ws);
+  void* out = d_out ? d_out : (void*)mp->d_out;
+  int rc = msm_run_ws(ctx, MsmWsSource{nullptr, 0}, d_scalars, nullptr, mp->n, 0, out, nullptr, &pr);
+  if (rc != BP_OK) return rc;
+  if (h_out) {
+    BP_TRY(hipMemcpyAsync(h_out, out, 64, hipMemcpyDeviceToHost, ctx->stream));
+    BP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return BP_OK;
 }
 
 }  // namespace bp

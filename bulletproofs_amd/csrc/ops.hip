@@ -274,6 +274,36 @@ int bp_msm_dev_static(bp_ctx* ctx, const void* d_scalars, const void* d_points, 
   return msm_run_static(ctx, d_scalars, d_points, n, window_bits, d_out);
 }
 
+int bp_msm_points_create(bp_ctx* ctx, const uint8_t* points, size_t n, bp_msm_points** out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(points && out, "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_points_create(ctx, points, nullptr, n, (MsmPoints**)out);
+}
+
+int bp_msm_points_create_dev(bp_ctx* ctx, const void* d_points, size_t n, bp_msm_points** out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(d_points && out, "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_points_create(ctx, nullptr, d_points, n, (MsmPoints**)out);
+}
+
+void bp_msm_points_destroy(bp_msm_points* mp) { msm_points_destroy((MsmPoints*)mp); }
+
+int bp_msm_points_run(bp_ctx* ctx, bp_msm_points* mp, const uint8_t* scalars, uint8_t* out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(mp && scalars && out, "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_points_run((MsmPoints*)mp, nullptr, scalars, nullptr, out);
+}
+
+int bp_msm_points_run_dev(bp_ctx* ctx, bp_msm_points* mp, const void* d_scalars, void* d_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(mp && d_scalars && d_out, "null pointer");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_points_run((MsmPoints*)mp, d_scalars, nullptr, d_out, nullptr);
+}
+
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
   if (!ctx) return BP_ERR_ARG;
   BP_REQUIRE(out && (n == 0 || (scalars && points)), "null pointer");

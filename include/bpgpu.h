@@ -108,6 +108,25 @@ int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok)
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
 int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
 
+/* ---- multi-scalar multiplication over a FIXED point list ----
+ * `sumExps es ps` where `ps` is the same list call after call - a Pedersen vector commitment over fixed generators,
+ * the shape of commitBitVectors (RangeProof/Internal.hs:136-147) and of BASELINE config 3 ("points uploaded once").
+ * bp_msm_points_create(_dev) uploads the n points once (host / device pointer) and precomputes, per point, the
+ * copies 2^(c w) P for the bucket method's windows (W x n x 64 B of HBM), so that every window's buckets carry
+ * weight 1: no window doublings and one bucket reduction instead of W.  Results are the same group elements as
+ * bp_msm's, byte for byte.
+ *   bp_msm_points_run      scalars in HOST memory (n x 32 B; pinned memory lets the upload overlap the recoding:
+ *                          it is cut into chunks, each recoded as soon as it has landed), out: 64 B host; synchronous
+ *   bp_msm_points_run_dev  scalars and the 64-byte result in device memory, asynchronous on the context's stream
+ * A handle belongs to the context it was created on; calls on one handle must not overlap.
+ */
+typedef struct bp_msm_points bp_msm_points;
+int bp_msm_points_create(bp_ctx* ctx, const uint8_t* points, size_t n, bp_msm_points** out);
+int bp_msm_points_create_dev(bp_ctx* ctx, const void* d_points, size_t n, bp_msm_points** out);
+void bp_msm_points_destroy(bp_msm_points* mp);
+int bp_msm_points_run(bp_ctx* ctx, bp_msm_points* mp, const uint8_t* scalars, uint8_t* out);
+int bp_msm_points_run_dev(bp_ctx* ctx, bp_msm_points* mp, const void* d_scalars, void* d_out);
+
 /* bp_point_sum_dev   d_out = sum of n affine points, device pointers, asynchronous on the context's stream: the fold
  *                   of `<>` over a list (the right-nested sum of Utils.hs:78-80 without the scalars).  Combines the
  *                   per-GPU partial sums of a sumExps whose point range is sharded over GPUs. */

@@ -108,3 +108,68 @@ def test_full_size_known_dlog(engine, logn):
     a = rng.randrange(2, R)
     got2 = _lib.dec_point(engine.msm_raw(_lib.enc_scalars([a * e % R for e in es]), pts_raw, n))
     assert got2 == o.point_mul(expect, a)
+
+
+# ---- bp_msm_points: a fixed point list prepared once (shifted copies, no window doublings) --------------------------
+@pytest.mark.parametrize("n", [1, 7, 300, 5000])
+def test_prepared_points_vs_oracle(engine, n):
+    """Same group element as sumExps, byte for byte, for several scalar vectors on one handle; O among the points,
+    scalars 0, 1, r - 1, values >= r (they act modulo r)."""
+    import torch
+    rng = random.Random(150 + n)
+    base = [o.point_mul(o.GEN, rng.randrange(1, R)) for _ in range(min(n, 12))]
+    ps = [rng.choice(base + [None]) for _ in range(n)]
+    mp = engine.msm_points(points=_lib.enc_points(ps))
+    d_out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    for rep in range(3):
+        es = [rng.choice([0, 1, R - 1, rng.randrange(R), rng.randrange(R), rng.randrange(2**64), R + 5])
+              for _ in range(n)]
+        exp = o.sum_exps([e % R for e in es], ps)
+        assert _lib.dec_point(mp.run(_lib.enc_scalars(es))) == exp
+        d_s = torch.frombuffer(bytearray(_lib.enc_scalars(es)), dtype=torch.uint8).cuda()
+        mp.run_dev(d_s.data_ptr(), d_out.data_ptr())
+        engine.sync()
+        assert _lib.dec_point(bytes(d_out.cpu().numpy())) == exp
+    mp.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "64bit", "01", "one_bucket"])
+def test_prepared_points_full_size_structured_scalars(engine, kind):
+    """2^18 points with known discrete logs: the result must be (sum e_i k_i mod r) * G for the scalar shapes of
+    BASELINE config 3 (uniform, 64-bit, {0,1}: the last two pile onto bucket 0, the wave-aggregated atomics and the
+    heavy-bucket path), through the chunked pinned-memory upload and through bp_msm_dev on the same inputs."""
+    import numpy as np
+    import torch
+    n = 1 << 18
+    rng = np.random.default_rng(160)
+    ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x7F
+    g = np.frombuffer(_lib.enc_point(o.GEN), dtype=np.uint8)
+    pts = np.frombuffer(engine.point_mul_raw(ks.tobytes(), np.tile(g, n).tobytes(), n), dtype=np.uint8).copy()
+    es = np.zeros((n, 32), dtype=np.uint8)
+    if kind == "uniform":
+        es[:] = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        es[:, 31] &= 0x7F
+    elif kind == "64bit":
+        es[:, :8] = rng.integers(0, 256, size=(n, 8), dtype=np.uint8)
+    elif kind == "01":
+        es[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint8)
+    else:
+        es[:, 2] = 3  # every scalar 3 * 2^16: one bucket of window 1 holds all entries
+    k_int = [int.from_bytes(bytes(r_), "little") for r_ in ks]
+    e_int = [int.from_bytes(bytes(r_), "little") for r_ in es]
+    exp = o.point_mul(o.GEN, sum(a * b for a, b in zip(e_int, k_int)) % R)
+    d_p = torch.from_numpy(pts).cuda()
+    mp = engine.msm_points(d_points=d_p.data_ptr(), n=n)
+    h_s = torch.from_numpy(es).pin_memory()
+    assert _lib.dec_point(mp.run(h_s.data_ptr())) == exp           # pinned host scalars: chunked upload
+    assert _lib.dec_point(mp.run(es.tobytes())) == exp             # pageable host scalars
+    d_s = h_s.cuda()
+    d_o = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    mp.run_dev(d_s.data_ptr(), d_o.data_ptr())
+    engine.sync()
+    assert _lib.dec_point(bytes(d_o.cpu().numpy())) == exp
+    engine.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, d_o.data_ptr())   # the plain bucket MSM on the same inputs
+    engine.sync()
+    assert _lib.dec_point(bytes(d_o.cpu().numpy())) == exp
+    mp.close()
