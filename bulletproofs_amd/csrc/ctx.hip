@@ -184,7 +184,7 @@ int bp_ctx_profile(bp_ctx* ctx, int enable) {
 
 int bp_ctx_profile_read(bp_ctx* ctx, int kernel, double* total_ms, uint64_t* launches, double* mixed_adds) {
   if (!ctx) return BP_ERR_ARG;
-  BP_REQUIRE(kernel == 0 || kernel == 1, "kernel must be 0 (k_fixed_multiexp) or 1 (k_light)");
+  BP_REQUIRE(kernel == 0 || kernel == 1, "kernel must be 0 (k_fixed_multiexp) or 1 (k_accumulate)");
   BP_REQUIRE(total_ms && launches && mixed_adds, "null pointer");
   if (kernel == 1 && ctx->prof_pending_light) {  // fold in the last MSM launch
     BP_TRY(hipSetDevice(ctx->device));

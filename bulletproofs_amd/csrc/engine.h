@@ -81,7 +81,7 @@ struct bp_ctx {
   void (*vjob_cache_free)(void*) = nullptr;
   // optional kernel timing with HIP events on the launching stream (bp_ctx_profile)
   int profile = 0;
-  double prof_ms[2] = {0, 0};        // [0] k_fixed_multiexp, [1] k_light
+  double prof_ms[2] = {0, 0};        // [0] k_fixed_multiexp, [1] k_accumulate
   uint64_t prof_calls[2] = {0, 0};
   double prof_madds[2] = {0, 0};     // mixed additions those launches performed (nominal)
   hipEvent_t msm_ev[2] = {nullptr, nullptr};

@@ -8,7 +8,7 @@
 //   3 k_scatter       counting-sort scatter: (point index | sign) grouped by bucket
 //   4 k_cls_*         counting sort of BUCKETS by population, descending, so that the
 //                     64 lanes of a wave own equally long lists (no divergence tail)
-//   5 k_light         one lane per bucket (population <= LIGHT_MAX): XYZZ mixed adds
+//   5 k_accumulate    one lane per bucket (population <= LIGHT_MAX): XYZZ mixed adds
 //     k_heavy_*       buckets above LIGHT_MAX are cut into slices, one workgroup per
 //                     slice (wave-level shuffle reduction + LDS across waves)
 //   6 k_seg_reduce    running-sum reduction of 32-bucket segments, one lane each
@@ -362,11 +362,10 @@ __global__ void __launch_bounds__(1024) k_cls_scatter(const uint32_t* __restrict
 
 // ---- 5a. light buckets: one lane per bucket ----------------------------------------
 // shift_stride != 0: `points` holds, for window w, the copies 2^(c w) P_i at points + w * shift_stride (bp_msm_points)
-__global__ void __launch_bounds__(256) k_light(const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
-                                              const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
-                                              const uint32_t* __restrict__ order, uint32_t total, uint32_t glv,
-                                              uint32_t nb, size_t shift_stride, xyzz* __restrict__ buckets) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void light_lane(uint32_t t, const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
+                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
+                                           const uint32_t* __restrict__ order, uint32_t total, uint32_t glv, uint32_t nb,
+                                           size_t shift_stride, xyzz* __restrict__ buckets) {
   if (t >= total) return;
   uint32_t bid = order[t];
   uint32_t cnt = hist[bid];
@@ -422,19 +421,17 @@ __global__ void __launch_bounds__(1024) k_heavy_plan(const uint32_t* __restrict_
   if (t == 0) heavy_off[nheavy] = base;
 }
 
-__global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict__ points,
-                                                     const uint32_t* __restrict__ hist,
-                                                     const uint32_t* __restrict__ offs,
-                                                     const uint32_t* __restrict__ sorted,
-                                                     const uint32_t* __restrict__ order,
-                                                     const uint32_t* __restrict__ bins,
-                                                     const uint32_t* __restrict__ heavy_off, uint32_t glv,
-                                                     uint32_t nb, size_t shift_stride, xyzz* __restrict__ partial) {
-  __shared__ xyzz lds[4];
+// slices [first, total) step `stride` of the heavy buckets, one workgroup per slice
+__device__ __forceinline__ void heavy_slices(uint32_t first, uint32_t stride, const uint8_t* __restrict__ points,
+                                             const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
+                                             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
+                                             const uint32_t* __restrict__ bins, const uint32_t* __restrict__ heavy_off,
+                                             uint32_t glv, uint32_t nb, size_t shift_stride, xyzz* __restrict__ partial,
+                                             xyzz* lds) {
   uint32_t nheavy = bins[2 * NBINS];
   if (nheavy == 0) return;
   uint32_t total = heavy_off[nheavy];
-  for (uint32_t j = blockIdx.x; j < total; j += gridDim.x) {
+  for (uint32_t j = first; j < total; j += stride) {
     // largest h with heavy_off[h] <= j
     uint32_t lo = 0, hi = nheavy - 1;
     while (lo < hi) {
@@ -456,6 +453,24 @@ __global__ void __launch_bounds__(256) k_heavy_slices(const uint8_t* __restrict_
     acc = block_sum(acc, lds);
     if (threadIdx.x == 0) st_xyzz(&partial[j], acc);
   }
+}
+
+// Bucket accumulation in ONE launch: the first heavy_blocks workgroups walk the slices of the heavy buckets (the narrow
+// top window of the GLV form always has some), the others run one lane per light bucket; the heavy slices used to
+// wait behind the light kernel in two launches of their own.
+__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
+                                                   const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
+                                                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ bins,
+                                                   const uint32_t* __restrict__ heavy_off, uint32_t total, uint32_t glv,
+                                                   uint32_t nb, size_t shift_stride, uint32_t heavy_blocks,
+                                                   xyzz* __restrict__ buckets, xyzz* __restrict__ partial) {
+  __shared__ xyzz lds[4];
+  if (blockIdx.x >= heavy_blocks)
+    light_lane((blockIdx.x - heavy_blocks) * blockDim.x + threadIdx.x, points, hist, offs, sorted, order, total, glv, nb,
+               shift_stride, buckets);
+  else
+    heavy_slices(blockIdx.x, heavy_blocks, points, hist, offs, sorted, order, bins, heavy_off, glv, nb, shift_stride, partial,
+                 lds);
 }
 
 // one wave per heavy bucket: sum its slice partials
@@ -834,19 +849,20 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
         ctx->prof_calls[1] += 1;
       }
     }
-    BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
   }
-  hipLaunchKernelGGL(k_light, dim3((nbt32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs,
-                     sorted, order, nbt32, glv, (uint32_t)pl.nb, shift_stride, buckets);
+  hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
+  if (profile) BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
+  {
+    const uint32_t light_blocks = (nbt32 + 255) / 256;
+    const uint32_t hgrid = (uint32_t)(max_slices < 1024 ? max_slices : 1024);
+    hipLaunchKernelGGL(k_accumulate, dim3(hgrid + light_blocks), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,
+                       order, bins, heavy_off, nbt32, glv, (uint32_t)pl.nb, shift_stride, hgrid, buckets, partial);
+  }
   if (profile) {
     BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
     ctx->prof_pending_light = true;
     ctx->prof_madds[1] += (double)wn;
   }
-  hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
-  uint32_t hgrid = (uint32_t)(max_slices < 4096 ? max_slices : 4096);
-  hipLaunchKernelGGL(k_heavy_slices, dim3(hgrid), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,
-                     order, bins, heavy_off, glv, (uint32_t)pl.nb, shift_stride, partial);
   uint32_t fgrid = (uint32_t)(max_heavy < 4096 ? max_heavy : 4096);
   hipLaunchKernelGGL(k_heavy_final, dim3(fgrid), dim3(64), 0, st, order, bins, heavy_off, partial, buckets);
   if (prep) {  // all windows weigh 1: add their buckets index by index, then reduce ONE window; no Horner chain

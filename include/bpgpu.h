@@ -66,7 +66,7 @@ int bp_ctx_queue_info(bp_ctx* ctx, int* hw_queues_env, int* pool_streams, int* c
 
 /* Kernel timing for the benchmark's roofline line: when enabled, the two dominant kernels are
  * bracketed with HIP events on the stream they are launched on.  kernel 0 = k_fixed_multiexp
- * (batch verifier), 1 = k_light (MSM bucket accumulation).  Returns the accumulated device
+ * (batch verifier), 1 = k_accumulate (MSM bucket accumulation).  Returns the accumulated device
  * time, launch count and the number of mixed point additions those launches performed.
  * bp_ctx_profile(ctx, x) also resets the counters.  No counterpart in the reference. */
 int bp_ctx_profile(bp_ctx* ctx, int enable);
