@@ -514,14 +514,17 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
     uint8_t pts[3][64];
     uint8_t sm[3][32];
   } res;
+  u256* d_sm = (u256*)(d_out + sizeof(res.pts));  // dot, l, r right behind the three points: one copy per round
   auto fetch = [&](bool points) -> int {
-    if (points) BP_TRY(hipMemcpyAsync(res.pts, d_out, sizeof(res.pts), hipMemcpyDeviceToHost, st));
-    BP_TRY(hipMemcpyAsync(res.sm, f.sm, sizeof(res.sm), hipMemcpyDeviceToHost, st));
+    if (points)
+      BP_TRY(hipMemcpyAsync(&res, d_out, sizeof(res), hipMemcpyDeviceToHost, st));
+    else
+      BP_TRY(hipMemcpyAsync(res.sm, d_sm, sizeof(res.sm), hipMemcpyDeviceToHost, st));
     BP_TRY(hipStreamSynchronize(st));
     return BP_OK;
   };
   if (n == 1) {  // ([l], [r]): no round, commitmentLR is never hashed (Prover.hs:43)
-    if ((rc = frv_ipp_round(ctx, n, 1, false, zero, zero, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, f.sm, false)) != BP_OK) return rc;
+    if ((rc = frv_ipp_round(ctx, n, 1, false, zero, zero, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, d_sm, false)) != BP_OK) return rc;
     if ((rc = fetch(false)) != BP_OK) return rc;
     if (dot0_out) memcpy(dot0_out, res.sm[0], 32);
     memcpy(l_out, res.sm[1], 32);
@@ -542,7 +545,7 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
   }
   // commitment of (ls, rs) under the folded base and the next lCommit / rCommit: three sums over the 2n + 1 generators
   auto launch = [&](uint32_t nk_prev, bool fold, const u256& x, const u256& xi) -> int {
-    int r2 = frv_ipp_round(ctx, n, nk_prev, fold, x, xi, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, f.sm, true);
+    int r2 = frv_ipp_round(ctx, n, nk_prev, fold, x, xi, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, d_sm, true);
     if (r2 != BP_OK) return r2;
     if ((r2 = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, d_out)) != BP_OK) return r2;
     return fetch(true);
@@ -567,7 +570,7 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
     if (nk > 2) {
       if ((rc = launch(nk, true, fr4_as_u256(x), fr4_as_u256(xi))) != BP_OK) return rc;
     } else {  // last fold: only l, r are left
-      if ((rc = frv_ipp_round(ctx, n, nk, true, fr4_as_u256(x), fr4_as_u256(xi), ubm, f.ls, f.rs, f.cg, f.ch, d_sc, f.sm,
+      if ((rc = frv_ipp_round(ctx, n, nk, true, fr4_as_u256(x), fr4_as_u256(xi), ubm, f.ls, f.rs, f.cg, f.ch, d_sc, d_sm,
                               false)) != BP_OK)
         return rc;
       if ((rc = fetch(false)) != BP_OK) return rc;
@@ -624,9 +627,10 @@ static int rangeproof_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t m
     return rc;
   if ((rc = fb_msm_launch(ctx, 2, nterms, w.sc, d_tb, d_part, nullptr, d_out)) != BP_OK) return rc;
   BP_TRY(hipMemcpyAsync(A, d_out, 128, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipStreamSynchronize(st));  // A, S are in; tb, bits live on this frame
+  // queued now, they run while the host hashes y and z
   if ((rc = frv_from_bytes(ctx, raw_sL, nm, l1)) != BP_OK) return rc;  // l1 = sL (Prover.hs:143)
   if ((rc = frv_from_bytes(ctx, raw_sR, nm, sRm)) != BP_OK) return rc;
-  BP_TRY(hipStreamSynchronize(st));  // A, S are in; tb, bits live on this frame
   // y, z   (Prover.hs:75-76)
   uint8_t buf[MSG_SCRATCH], keep[MSG_SCRATCH], yb[32], zb[32], xb[32];
   Msg my(buf, style);
@@ -646,9 +650,11 @@ static int rangeproof_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t m
   if ((rc = frv_rp_tpoly(ctx, nm, l0, l1, r0, r1, f.sm + 8)) != BP_OK) return rc;
   uint8_t tpoly[3][32];
   BP_TRY(hipMemcpyAsync(tpoly, f.sm + 8, sizeof(tpoly), hipMemcpyDeviceToHost, st));
-  // hs' = hs_i * recip(y^i) (Prover.hs:107) enters the inner-product argument as scalar factors
-  if ((rc = frv_power_vector(ctx, fr4_as_u256(fr_inv(y)), nm, hscale)) != BP_OK) return rc;
+  const Fr4 yinv = fr_inv(y);  // while the kernels run
   BP_TRY(hipStreamSynchronize(st));
+  // hs' = hs_i * recip(y^i) (Prover.hs:107) enters the inner-product argument as scalar factors; runs behind the
+  // host's work on T1, T2
+  if ((rc = frv_power_vector(ctx, fr4_as_u256(yinv), nm, hscale)) != BP_OK) return rc;
   const Fr4 t0 = fr_from_bytes(tpoly[0]), t1 = fr_from_bytes(tpoly[1]), t2 = fr_from_bytes(tpoly[2]);
   // t1Commit = commit t1 t1Blinding, t2Commit likewise   (Prover.hs:84-85; Utils.hs:84-85)
   {
