@@ -253,6 +253,29 @@ BP_HD xyzz glv_split_lane(const u256& k0, const u256& k1, const xyzz& P0s, const
   return acc;
 }
 
+// ---- k*P with one lane per bit -------------------------------------------------------------------------------
+// Lane j < GLV_LANE_BITS holds Tj = 2^j P (XYZZ) and contributes [bit j of |k1|] (+-Tj) + [bit j of |k2|] (+-phi(Tj)),
+// k = k1 + k2*lambda the signed split: no doubling and at most one addition per lane, and the lanes' terms add up
+// to k*P.  |k1|, |k2| < 2^128 (glv_split); the spare bit 128 the halves carry is served by the last lane.
+constexpr int GLV_LANE_BITS = 128;
+BP_HD xyzz glv_bit_lane(const GlvHalf& h1, const GlvHalf& h2, const xyzz& Tj, int j) {
+  xyzz acc = xyzz_inf();
+  if (mag_bit(h1.m, j)) acc = h1.neg ? xyzz_neg(Tj) : Tj;
+  if (mag_bit(h2.m, j)) {
+    xyzz q = xyzz_phi(Tj);
+    acc = xyzz_add(acc, h2.neg ? xyzz_neg(q) : q);
+  }
+  if (j == GLV_LANE_BITS - 1 && ((h1.m[4] | h2.m[4]) & 1u)) {
+    xyzz t2 = xyzz_dbl(Tj);
+    if (h1.m[4] & 1u) acc = xyzz_add(acc, h1.neg ? xyzz_neg(t2) : t2);
+    if (h2.m[4] & 1u) {
+      xyzz q = xyzz_phi(t2);
+      acc = xyzz_add(acc, h2.neg ? xyzz_neg(q) : q);
+    }
+  }
+  return acc;
+}
+
 // Host-testable construction of that table (the device builds it with one shared inversion, verify.hip):
 // tab[e], e in [1, 16); tab[0] unused.
 BP_HD void glv_pair_table_local(const affine& P0, const affine& P1, affine* tab) {

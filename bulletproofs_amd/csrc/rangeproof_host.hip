@@ -326,12 +326,20 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
             const size_t pr[2] = {p, two ? p + 1 : p};
             Msg mm[2] = {Msg(buf0, st), Msg(buf1, st)};
             for (int i = 0; i < 2; i++) {
-              // every number of this message was formatted on the GPU (dec.h records): L_r, R_r beside
-              // stage 1, the running commitment by the kernel that produced it
               mm[i].r();
-              mm[i].point_rec(ch.lr_txt + ((size_t)r * B + pr[i]) * 160);
-              mm[i].point_rec(ch.lr_txt + ((size_t)(k + r) * B + pr[i]) * 160);
-              mm[i].point_rec(ch.acc_txt + pr[i] * 160);
+              if (ch.vb->split) {
+                // latency path: the host formats the three points itself (the commitment was normalised by
+                // vbatch_collect a moment ago)
+                mm[i].point(ch.pts + ((size_t)(VP_L0 + r) * B + pr[i]) * 64);
+                mm[i].point(ch.pts + ((size_t)(VP_L0 + k + r) * B + pr[i]) * 64);
+                mm[i].point(ch.acc + pr[i] * 64);
+              } else {
+                // every number of this message was formatted on the GPU (dec.h records): L_r, R_r beside
+                // stage 1, the running commitment by the kernel that produced it
+                mm[i].point_rec(ch.lr_txt + ((size_t)r * B + pr[i]) * 160);
+                mm[i].point_rec(ch.lr_txt + ((size_t)(k + r) * B + pr[i]) * 160);
+                mm[i].point_rec(ch.acc_txt + pr[i] * 160);
+              }
             }
             finish_fr_pair(mm[0], r_mid, ch.xk + p * 32, mm[1], r_mid, two ? ch.xk + (p + 1) * 32 : spare);
           }
@@ -393,6 +401,7 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
       if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc, ch.acc_txt, ch.lr_txt)) != BP_OK) return rc;
     } else if (stage[pick] <= k) {
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;  // completed already: folds the profiling events in
+      if ((rc = vbatch_collect(ch.vb, ch.acc)) != BP_OK) return rc;
       uint32_t r = stage[pick] - 1;
       // round 0 hashes the text of L_0, R_0 that k_dec_numbers wrote on the SIDE stream: join it first
       if (r == 0 && (rc = vbatch_join_side(ch.vb)) != BP_OK) return rc;

@@ -59,9 +59,15 @@ struct bp_vbatch {
   uint8_t* rtab;
   bp::xyzz* rtx;
   bp::u256* rpre;
-  // small batches (B <= 16): the rounds run through eight lanes per proof on shifted forms of L_r, R_r
+  // small batches (B <= VSPLIT_MAX_B): latency path.  Every variable-base product runs one lane per scalar bit on the
+  // bit tables sh[point][128] = 2^j * point of the proof's points (rows VP_S..), the running commitment stays in
+  // XYZZ on the device (acc_x) and is normalised by the host from the pinned copy hx, and the host supplies the
+  // field inversions (hinv: y^-1, (y-1)^-1, x_r^-1 per proof, pinned) it can do in microseconds.
   bool split;
-  bp::xyzz *rsh, *rsplit_tab, *fpart;  // fpart: workgroup sums of the lane-per-term fixed-base kernel
+  bp::xyzz *sh, *acc_x, *fpart;  // fpart: workgroup sums of the flat fixed-base kernel
+  bp::xyzz* hx;                  // pinned [B]
+  uint8_t* hinv;                 // pinned [3][B][32], Montgomery form
+  bool collect_pending;          // hx holds a commitment the caller has not been given yet (vbatch_collect)
   uint32_t nt1, nt3a, nt3b, npts;
   int stage;  // 0 created, 1 loaded, 2 begun, 2+r after r rounds
   // buffers of the *_async calls are pinned host memory: kernels read challenges from and store results to them directly
@@ -89,6 +95,9 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
 int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
 int vbatch_wait(bp_vbatch* vb);
+// After vbatch_wait of a begin or round stage: the commitment as affine bytes in out_commitment ([B][64]).  Batches
+// on the latency path (vb->split) normalise on the host here; for the others the kernels have written it already.
+int vbatch_collect(bp_vbatch* vb, uint8_t* out_commitment);
 // joins the side stream of vbatch_prepare_async (L_r, R_r text, round tables); call before hashing round 0
 int vbatch_join_side(bp_vbatch* vb);
 // has everything enqueued by the last *_async call completed?  (non-blocking)

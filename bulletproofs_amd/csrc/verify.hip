@@ -15,6 +15,7 @@
 //
 // Data layout: every per-proof array is [field][proof] (proof fastest) so a wave
 // of 64 proofs reads and writes contiguous lines.
+#include <string.h>
 #include "engine.h"
 #include "batchinv.h"
 #include "dec.h"
@@ -276,36 +277,37 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
   if (live && sub == 0) st_xyzz(&acc_out[p], acc);
 }
 
-// Small batches with many terms: 64 lanes per proof leave hundreds of additions per lane.  One lane per term
-// instead (all windows of its digits), workgroup sums into part[p][block], k_fixed_sum adds the workgroups.
+// Small batches: the (term, window) digits of a proof strided over gridDim.x workgroups of 256 lanes, a handful of
+// mixed additions per lane; workgroup sums into part[p][block] (or straight into acc_out when one workgroup
+// covers the proof), k_fixed_sum adds the workgroups.
 template <int WB>
-__global__ void __launch_bounds__(256) k_fixed_terms(uint32_t B, uint32_t nterms, const uint32_t* __restrict__ dig,
-                                                    const uint32_t* __restrict__ term_base, const uint8_t* __restrict__ table,
-                                                    xyzz* __restrict__ part /*[B][gridDim.x]*/) {
+__global__ void __launch_bounds__(256) k_fixed_flat(uint32_t B, uint32_t nterms, const uint32_t* __restrict__ dig,
+                                                   const uint32_t* __restrict__ term_base, const uint8_t* __restrict__ table,
+                                                   xyzz* __restrict__ part /*[B][gridDim.x]*/, xyzz* __restrict__ acc_out) {
   constexpr int W = fb_windows(WB), E = fb_entries(WB), DW = fb_dwords(WB), SLOT = fb_slot_bits(WB), PER = 32 / SLOT;
   __shared__ xyzz red[4];
-  const uint32_t p = blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t p = blockIdx.y, nf = nterms * (uint32_t)W;
   xyzz acc = xyzz_inf();
-  if (t < nterms) {
-    const size_t row0 = (size_t)term_base[t] * W * E;
 #pragma unroll 1
-    for (int w = 0; w < W; w++) {
-      uint32_t word = dig[((size_t)t * DW + (w / PER)) * B + p];
-      uint32_t code = SLOT == 32 ? word : ((word >> ((SLOT * (w % PER)) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
-      if (code == 0) continue;
-      bool neg;
-      uint32_t mag = fb_decode<WB>(code, neg);
-      bucket_add(acc, ld_affine(table + (row0 + (size_t)w * E + (mag - 1)) * 64), neg);
-    }
+  for (uint32_t f = blockIdx.x * 256u + threadIdx.x; f < nf; f += gridDim.x * 256u) {
+    const uint32_t term = f / (uint32_t)W, w = f - term * (uint32_t)W;
+    uint32_t word = dig[((size_t)term * DW + (w / PER)) * B + p];
+    uint32_t code = SLOT == 32 ? word : ((word >> ((SLOT * (w % PER)) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
+    if (code == 0) continue;
+    bool neg;
+    uint32_t mag = fb_decode<WB>(code, neg);
+    bucket_add(acc, ld_affine(table + (((size_t)term_base[term] * W + w) * E + (mag - 1)) * 64), neg);
   }
   xyzz sum = block_sum(acc, red);
-  if (threadIdx.x == 0) st_xyzz(&part[(size_t)p * gridDim.x + blockIdx.x], sum);
+  if (threadIdx.x == 0) st_xyzz(gridDim.x == 1 ? &acc_out[p] : &part[(size_t)p * gridDim.x + blockIdx.x], sum);
 }
-__global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk, const xyzz* __restrict__ part, xyzz* __restrict__ acc_out) {
+__global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk /* <= 64 */, const xyzz* __restrict__ part, xyzz* __restrict__ acc_out) {
   const uint32_t p = blockIdx.x;
   xyzz acc = xyzz_inf();
-  for (uint32_t i = threadIdx.x; i < nblk; i += 64u) acc = xyzz_add(acc, ld_xyzz(&part[(size_t)p * nblk + i]));
-  acc = wave_sum(acc);
+  if (threadIdx.x < nblk) acc = ld_xyzz(&part[(size_t)p * nblk + threadIdx.x]);
+  int width = 1;
+  while ((uint32_t)width < nblk) width <<= 1;
+  acc = wave_sum_width(acc, width);
   if (threadIdx.x == 0) st_xyzz(&acc_out[p], acc);
 }
 
@@ -483,101 +485,145 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   if (host_txt) block_store_point_text(lds, out, host_txt, d.B);
 }
 
-// ---- small batches: a round through eight lanes per proof (glv.h, glv_split_lane) -------------------------
-// With a handful of proofs the 129-step chain of k_round leaves the GPU idle and sets the latency of a
-// verification.  The proof's L_r, R_r are known before any challenge: k_vshift computes 2^(17 s) * P for s < 8
-// once (side stream, beside stage 1), and k_round_split gives every proof one wave whose lanes 0..7 each walk
-// 17 bits of the four GLV halves on the shifted points; a shuffle sum, the old commitment, one normalisation.
+// ---- small batches: the latency path ------------------------------------------------------------------------
+// With a handful of proofs the 129-step chains of k_round / k_stage1_tail / k_var_terms leave the GPU idle and set
+// the latency of a verification.  Every point of a proof (S, T1, T2, L_r, R_r, V_j) is known before any challenge:
+// k_vshift_bits writes 2^j * point for j < 128 once per pass (side stream, beside the host's first hashes), and a
+// product k * point is then one lane per bit (glv.h, glv_bit_lane: at most one addition) and a workgroup sum.
+// The field inversions of the path (y^-1, (y - 1)^-1, x_r^-1, and the normalisation of each running commitment)
+// are done by the host between its hashes, microseconds each against ~0.14 ms for one lane of the GPU.
 constexpr uint32_t VSPLIT_MAX_B = 16;
+enum { HI_YINV = 0, HI_YM1INV = 1, HI_XINV = 2 };
 
-__global__ void __launch_bounds__(64) k_vshift(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][SPLIT_S]*/) {
+// bit-table index of row `row` (>= VP_S) of proof p
+__device__ __forceinline__ size_t sh_index(uint32_t row, size_t B, uint32_t p) { return ((size_t)(row - VP_S) * B + p) * GLV_LANE_BITS; }
+
+__global__ void __launch_bounds__(64) k_vshift_bits(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][128]*/) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   xyzz a = xyzz_from_affine(ld_affine(pts + (size_t)i * 64));
-  st_xyzz(&sh[(size_t)i * SPLIT_S], a);
+  st_xyzz(&sh[(size_t)i * GLV_LANE_BITS], a);
 #pragma unroll 1
-  for (int s = 1; s < SPLIT_S; s++) {
-#pragma unroll 1
-    for (int b = 0; b < SPLIT_W; b++) a = xyzz_dbl(a);
-    st_xyzz(&sh[(size_t)i * SPLIT_S + s], a);
+  for (int j = 1; j < GLV_LANE_BITS; j++) {
+    a = xyzz_dbl(a);
+    st_xyzz(&sh[(size_t)i * GLV_LANE_BITS + j], a);
   }
 }
 
-__global__ void __launch_bounds__(64) k_round_split(VDims d, uint32_t round, const uint8_t* __restrict__ xk,
-                                                   u256* __restrict__ xk_m, u256* __restrict__ xkinv_m,
-                                                   const xyzz* __restrict__ sh /*[2k][B][SPLIT_S]*/,
-                                                   xyzz* __restrict__ tab /*[B][15][64]*/, uint8_t* __restrict__ acc_aff,
-                                                   uint8_t* __restrict__ host_out, uint8_t* __restrict__ host_txt) {
-  const uint32_t p = blockIdx.x;
-  const int s = threadIdx.x;
-  const size_t B = d.B;
-  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
-  u256 xinv = Fr::inv(x);
-  u256 x2 = Fr::sqr(x);
-  xyzz acc = xyzz_inf();
-  if (s < SPLIT_S) {
-    auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s], v); };
-    auto load = [&](int e) { return ld_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s]); };
-    acc = glv_split_lane(Fr::from_mont(x2), Fr::from_mont(Fr::sqr(xinv)),
-                         ld_xyzz(&sh[((size_t)round * B + p) * SPLIT_S + s]),
-                         ld_xyzz(&sh[((size_t)(d.k + round) * B + p) * SPLIT_S + s]), s, store, load);
+// this lane's term of k * point (k canonical), the point given by its bit table
+__device__ __forceinline__ xyzz bit_lane_term(const u256& k, const xyzz* __restrict__ tab, int j) {
+  GlvHalf h1, h2;
+  glv_split(k, h1, h2);
+  return glv_bit_lane(h1, h2, ld_xyzz(&tab[j]), j);
+}
+
+// thread per proof: k_vprep0 with the host's inversions (hinv) and the closed-form power sum
+__global__ void __launch_bounds__(64) k_vprep0_split(VDims d, const uint8_t* __restrict__ chal /*[4][B][32]*/,
+                                                    const uint8_t* __restrict__ hinv, u256* __restrict__ cst,
+                                                    u256* __restrict__ zpow /*[m+3][B]*/) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  size_t B = d.B;
+  u256 y = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)0 * B + p) * 32)));
+  u256 zp = Fr::reduce_once(ld_u256(chal + ((size_t)1 * B + p) * 32));
+  u256 z = Fr::to_mont(zp);
+  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)2 * B + p) * 32)));
+  u256 u = Fr::to_mont(Fr::reduce_once(ld_u256(chal + ((size_t)3 * B + p) * 32)));
+  stm(cst, C_ZP * B + p, zp);
+  stm(cst, C_Y * B + p, y);
+  stm(cst, C_Z * B + p, z);
+  stm(cst, C_X * B + p, x);
+  stm(cst, C_U * B + p, u);
+  stm(cst, C_YINV * B + p, ld_u256(hinv + ((size_t)HI_YINV * B + p) * 32));
+  stm(cst, C_X2 * B + p, Fr::sqr(x));
+  // sum_i y^i, i < nm, in closed form (y^nm - 1) / (y - 1), nm a power of two; y = 1 gives nm (as k_vprep0)
+  u256 ynm = y;
+  for (uint32_t j = 0; j < d.k; j++) ynm = Fr::sqr(ynm);
+  u256 ym1 = Fr::sub(y, Fr::one());
+  u256 ysum;
+  if (u256_is_zero(ym1)) {
+    u256 nmv = u256_zero();
+    nmv.v[0] = d.nm;
+    ysum = Fr::to_mont(nmv);
+  } else {
+    ysum = Fr::mul(Fr::sub(ynm, Fr::one()), ld_u256(hinv + ((size_t)HI_YM1INV * B + p) * 32));
   }
-  acc = wave_sum(acc);  // lanes >= SPLIT_S hold the identity
-  if (s == 0) {
+  u256 zc = Fr::one();
+  for (uint32_t e = 0; e < d.m + 3; e++) {
+    stm(zpow, (size_t)e * B + p, zc);
+    zc = Fr::mul(zc, z);
+  }
+  u256 z2 = Fr::sqr(z);
+  u256 two_n = u256_zero();
+  two_n.v[d.n >> 5] = 1u << (d.n & 31);
+  u256 tn1 = Fr::sub(Fr::to_mont(Fr::reduce_once(two_n)), Fr::one());
+  u256 zs = u256_zero(), zj = Fr::mul(z2, z);
+  for (uint32_t j = 0; j < d.m; j++) {
+    zs = Fr::add(zs, zj);
+    zj = Fr::mul(zj, z);
+  }
+  stm(cst, C_DELTA * B + p, Fr::sub(Fr::mul(Fr::sub(z, z2), ysum), Fr::mul(zs, tn1)));
+}
+
+// P = acc1 + x*S + A (computeLRCommitment), one workgroup of 128 lanes per proof; XYZZ to acc_x and the pinned copy
+__global__ void __launch_bounds__(128) k_stage1_tail_bits(VDims d, const uint8_t* __restrict__ pts, const u256* __restrict__ cst,
+                                                         const xyzz* __restrict__ acc1, const xyzz* __restrict__ sh,
+                                                         xyzz* __restrict__ acc_x, xyzz* __restrict__ hx) {
+  __shared__ xyzz red[2];
+  const uint32_t p = blockIdx.x;
+  const size_t B = d.B;
+  xyzz term = bit_lane_term(Fr::from_mont(ldm(cst, C_X * B + p)), sh + sh_index(VP_S, B, p), (int)threadIdx.x);
+  xyzz sum = block_sum(term, red);
+  if (threadIdx.x == 0) {
+    sum = xyzz_add(sum, ld_xyzz(&acc1[p]));
+    sum = xyzz_madd(sum, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
+    st_xyzz(&acc_x[p], sum);
+    st_xyzz(&hx[p], sum);
+  }
+}
+
+// acc <- x_r^2 L_r + x_r^-2 R_r + acc (InnerProductProof/Verifier.hs:49), 256 lanes per proof: lanes 0..127 the bits
+// of x_r^2 on L_r, lanes 128..255 those of x_r^-2 on R_r
+__global__ void __launch_bounds__(256) k_round_bits(VDims d, uint32_t round, const uint8_t* __restrict__ xk,
+                                                   const uint8_t* __restrict__ hinv, u256* __restrict__ xk_m,
+                                                   u256* __restrict__ xkinv_m, const xyzz* __restrict__ sh,
+                                                   xyzz* __restrict__ acc_x, xyzz* __restrict__ hx) {
+  __shared__ xyzz red[4];
+  const uint32_t p = blockIdx.x;
+  const size_t B = d.B;
+  const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
+  u256 x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
+  u256 xinv = ld_u256(hinv + ((size_t)HI_XINV * B + p) * 32);
+  u256 x2 = Fr::sqr(x);
+  u256 k = Fr::from_mont(side == 0 ? x2 : Fr::sqr(xinv));
+  xyzz term = bit_lane_term(k, sh + sh_index(VP_L0 + (side ? d.k : 0) + round, B, p), j);
+  xyzz sum = block_sum(term, red);
+  if (t == 0) {
     stm(xk_m, (size_t)round * B + p, x2);
     stm(xkinv_m, (size_t)round * B + p, xinv);
-    acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
-    affine out = xyzz_to_affine(acc);
-    st_affine(acc_aff + (size_t)p * 64, out);
-    if (host_out) st_affine(host_out + (size_t)p * 64, out);
-    if (host_txt) {
-      uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
-      u256_to_dec_record(out.x, wx);
-      u256_to_dec_record(out.y, wy);
-      uint4* t = (uint4*)(host_txt + (size_t)p * 2 * DEC_REC);
-#pragma unroll
-      for (int i = 0; i < DEC_REC_WORDS / 4; i++) {
-        t[i] = make_uint4(wx[4 * i], wx[4 * i + 1], wx[4 * i + 2], wx[4 * i + 3]);
-        t[DEC_REC_WORDS / 4 + i] = make_uint4(wy[4 * i], wy[4 * i + 1], wy[4 * i + 2], wy[4 * i + 3]);
-      }
-    }
+    sum = xyzz_add(sum, ld_xyzz(&acc_x[p]));
+    st_xyzz(&acc_x[p], sum);
+    st_xyzz(&hx[p], sum);
   }
 }
 
-// stage 1 tail of a small batch: P = acc1 + x*S + A with x*S through the eight lanes (S shifted by k_vshift)
-__global__ void __launch_bounds__(64) k_stage1_tail_split(VDims d, const uint8_t* __restrict__ pts, const u256* __restrict__ cst,
-                                                         const xyzz* __restrict__ acc1, const xyzz* __restrict__ shS /*[B][SPLIT_S]*/,
-                                                         xyzz* __restrict__ tab /*[B][15][64]*/, uint8_t* __restrict__ acc_aff,
-                                                         uint8_t* __restrict__ host_out, uint8_t* __restrict__ host_txt) {
+// acc2 += sum over the m + 2 variable-base terms of E2 (V_0..V_{m-1}, T1, T2 with the scalars vs of k_vprep_t), 256
+// lanes per proof: two terms per pass over the bit positions, one workgroup sum at the end
+__global__ void __launch_bounds__(256) k_tcheck_bits(VDims d, const uint8_t* __restrict__ vs, const xyzz* __restrict__ sh,
+                                                    xyzz* __restrict__ acc2) {
+  __shared__ xyzz red[4];
   const uint32_t p = blockIdx.x;
-  const int s = threadIdx.x;
   const size_t B = d.B;
+  const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
+  const uint32_t nv = d.m + 2;
   xyzz acc = xyzz_inf();
-  if (s < SPLIT_S) {
-    auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s], v); };
-    auto load = [&](int e) { return ld_xyzz(&tab[((size_t)p * 15 + (e - 1)) * 64 + s]); };
-    acc = glv_split_lane(Fr::from_mont(ldm(cst, C_X * B + p)), u256_zero(), ld_xyzz(&shS[(size_t)p * SPLIT_S + s]),
-                         xyzz_inf(), s, store, load);
+#pragma unroll 1
+  for (uint32_t term = (uint32_t)side; term < nv; term += 2) {
+    uint32_t row = term < d.m ? VP_L0 + 2 * d.k + term : (term == d.m ? VP_T1 : VP_T2);
+    acc = xyzz_add(acc, bit_lane_term(ld_u256(vs + ((size_t)term * B + p) * 32), sh + sh_index(row, B, p), j));
   }
-  acc = wave_sum(acc);
-  if (s == 0) {
-    acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
-    acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
-    affine out = xyzz_to_affine(acc);
-    st_affine(acc_aff + (size_t)p * 64, out);
-    if (host_out) st_affine(host_out + (size_t)p * 64, out);
-    if (host_txt) {
-      uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
-      u256_to_dec_record(out.x, wx);
-      u256_to_dec_record(out.y, wy);
-      uint4* t = (uint4*)(host_txt + (size_t)p * 2 * DEC_REC);
-#pragma unroll
-      for (int i = 0; i < DEC_REC_WORDS / 4; i++) {
-        t[i] = make_uint4(wx[4 * i], wx[4 * i + 1], wx[4 * i + 2], wx[4 * i + 3]);
-        t[DEC_REC_WORDS / 4 + i] = make_uint4(wy[4 * i], wy[4 * i + 1], wy[4 * i + 2], wy[4 * i + 3]);
-      }
-    }
-  }
+  xyzz sum = block_sum(acc, red);
+  if (t == 0) st_xyzz(&acc2[p], xyzz_add(sum, ld_xyzz(&acc2[p])));
 }
 
 // mkOtherExponents (Verifier.hs:55-73): s_i = s0 * prod_{bit j of i} x_{k-1-j}^2, s0 = prod_k x_k^-1 (challenges are
@@ -699,12 +745,14 @@ __global__ void __launch_bounds__(256) k_vcheck(uint32_t B, uint32_t npts, const
 
 // verdict[p] = (acc1 == acc_k) && (acc2 == O) && the proof's encoding was valid
 __global__ void __launch_bounds__(256) k_verdict(VDims d, const xyzz* __restrict__ acc1, const xyzz* __restrict__ acc2,
-                                                const uint8_t* __restrict__ acc_aff, const uint8_t* __restrict__ bad,
-                                                uint8_t* __restrict__ verdict,
+                                                const uint8_t* __restrict__ acc_aff, const xyzz* __restrict__ acc_x,
+                                                const uint8_t* __restrict__ bad, uint8_t* __restrict__ verdict,
                                                 uint8_t* __restrict__ host_out /*pinned host copy, or null*/) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
-  xyzz e1 = xyzz_madd(ld_xyzz(&acc1[p]), affine_neg(ld_affine(acc_aff + (size_t)p * 64)));
+  // the running commitment: affine bytes, or (latency path) XYZZ
+  xyzz e1 = acc_x ? xyzz_add(ld_xyzz(&acc1[p]), xyzz_neg(ld_xyzz(&acc_x[p])))
+                  : xyzz_madd(ld_xyzz(&acc1[p]), affine_neg(ld_affine(acc_aff + (size_t)p * 64)));
   bool ok = xyzz_is_inf(e1) && xyzz_is_inf(ld_xyzz(&acc2[p])) && bad[p] == 0;
   verdict[p] = ok ? 1 : 0;
   if (host_out) host_out[p] = ok ? 1 : 0;
@@ -736,18 +784,20 @@ static inline void launch_fixed(bp_vbatch* vb, size_t nthreads, uint32_t nterms,
                                 const uint32_t* tb, xyzz* acc, hipStream_t strm = nullptr) {
   const uint8_t* table = vb->ctx->d_table;
   if (!strm) strm = vb->stream;
-  if (vb->split && nterms >= 512 && lpp > 1) {  // few proofs, many terms: one lane per term, two launches
-    const uint32_t nblk = (nterms + 255) / 256;
+  if (vb->split) {  // few proofs: about six mixed additions per lane
+    const uint32_t nf = nterms * (uint32_t)(fb_windows((int)vb->d.wb));
+    uint32_t nblk = (nf + 256u * 6u - 1) / (256u * 6u);
+    nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     dim3 grid(nblk, vb->d.B), block(256);
     if (vb->d.wb == 20)
-      hipLaunchKernelGGL(k_fixed_terms<20>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+      hipLaunchKernelGGL(k_fixed_flat<20>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart, acc);
     else if (vb->d.wb == 16)
-      hipLaunchKernelGGL(k_fixed_terms<16>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+      hipLaunchKernelGGL(k_fixed_flat<16>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart, acc);
     else if (vb->d.wb == 12)
-      hipLaunchKernelGGL(k_fixed_terms<12>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
+      hipLaunchKernelGGL(k_fixed_flat<12>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart, acc);
     else
-      hipLaunchKernelGGL(k_fixed_terms<8>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart);
-    hipLaunchKernelGGL(k_fixed_sum, dim3(vb->d.B), dim3(64), 0, strm, nblk, vb->fpart, acc);
+      hipLaunchKernelGGL(k_fixed_flat<8>, grid, block, 0, strm, vb->d.B, nterms, dig, tb, table, vb->fpart, acc);
+    if (nblk > 1) hipLaunchKernelGGL(k_fixed_sum, dim3(vb->d.B), dim3(64), 0, strm, nblk, vb->fpart, acc);
     return;
   }
   if (vb->d.wb == 20)
@@ -769,6 +819,10 @@ static inline void launch_tcheck(bp_vbatch* vb, hipStream_t strm) {
   launch_fixed(vb, B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, vb->acc2, strm);
   uint32_t nv = d.m + 2;
   uint32_t j = 0;
+  if (vb->split) {
+    hipLaunchKernelGGL(k_tcheck_bits, dim3(d.B), dim3(256), 0, strm, d, vb->vs, vb->sh, vb->acc2);
+    return;
+  }
   if (nv & 1u) {  // m = 1: three terms, one pass of three
     hipLaunchKernelGGL(k_var_terms<3>, VB_GRID_ON(B, strm), d, 0u, vb->pts, vb->vs, vb->vtab2, vb->acc2);
     j = 3;
@@ -809,22 +863,20 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
   }
   VDims d = vb->d;
   size_t B = d.B;
-  if (d.k == 0 || vb->tab_pending) return BP_OK;
+  if ((d.k == 0 && !vb->split) || vb->tab_pending) return BP_OK;
   if (vb->t_pending) {  // a previous pass's side work
     BP_TRY(hipStreamSynchronize(vb->aux));
     vb->t_pending = false;
   }
-  if (lr_text && vb->direct_host) {
-    size_t cnt = (size_t)2 * d.k * B * 2;
-    hipLaunchKernelGGL(k_dec_numbers, VB_GRID_ON(cnt, vb->aux), vb->pts + (size_t)VP_L0 * B * 64, (uint32_t)cnt, lr_text);
-  }
   if (vb->split) {
-    const uint32_t cnt = 2 * d.k * d.B;
-    // S first (stage 1 needs it), then the rows L_r, R_r
-    hipLaunchKernelGGL(k_vshift, dim3((d.B + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_S * B * 64, d.B,
-                       vb->rsh + (size_t)cnt * SPLIT_S);
-    hipLaunchKernelGGL(k_vshift, dim3((cnt + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_L0 * B * 64, cnt, vb->rsh);
+    // every row from S on; the host formats L_r, R_r itself on this path (no text kernel)
+    const uint32_t cnt = (vb->npts - VP_S) * d.B;
+    hipLaunchKernelGGL(k_vshift_bits, dim3((cnt + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_S * B * 64, cnt, vb->sh);
   } else {
+    if (lr_text && vb->direct_host) {
+      size_t cnt = (size_t)2 * d.k * B * 2;
+      hipLaunchKernelGGL(k_dec_numbers, VB_GRID_ON(cnt, vb->aux), vb->pts + (size_t)VP_L0 * B * 64, (uint32_t)cnt, lr_text);
+    }
     hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
   }
   BP_TRY(hipGetLastError());
@@ -860,30 +912,44 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
     BP_TRY(hipMemcpyAsync(vb->chal, challenges, 4 * B * 32, hipMemcpyHostToDevice, vb->stream));
     chal = vb->chal;
   }
-  const bool ladder = !(vb->split && d.nm >= 256);
-  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow, ladder);
-  if (!ladder) hipLaunchKernelGGL(k_vprep0_pow, VB_GRID((size_t)d.nm * B), d, vb->cst, vb->ypowinv);
-  hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   uint32_t lpp = vbatch_lpp(d.B);
+  uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
+  if (vb->split) {
+    // the two inversions of this stage on the host (`challenges` is host memory in both modes)
+    for (size_t p = 0; p < B; p++) {
+      u256 y;
+      memcpy(&y, challenges + ((size_t)0 * B + p) * 32, 32);
+      y = Fr::to_mont(Fr::reduce_once(y));
+      u256 yi = Fr::inv(y), ym1i = Fr::inv(Fr::sub(y, Fr::one()));
+      memcpy(vb->hinv + ((size_t)HI_YINV * B + p) * 32, &yi, 32);
+      memcpy(vb->hinv + ((size_t)HI_YM1INV * B + p) * 32, &ym1i, 32);
+    }
+    hipLaunchKernelGGL(k_vprep0_split, dim3((d.B + 63) / 64), dim3(64), 0, vb->stream, d, chal, vb->hinv, vb->cst, vb->zpow);
+    hipLaunchKernelGGL(k_vprep0_pow, VB_GRID((size_t)d.nm * B), d, vb->cst, vb->ypowinv);
+    hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
+    launch_fixed(vb, B * lpp, vb->nt1, lpp, vb->dig1, vb->tb1, vb->acc1);
+    // the bit tables come from the side stream (launched at prepare, ~0.5 ms of doublings): host-side join, which
+    // also covers the rounds' and the t-check's needs
+    if (vb->tab_pending && vb->aux != vb->stream) BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->tab_pending = false;
+    hipLaunchKernelGGL(k_stage1_tail_bits, dim3(d.B), dim3(128), 0, vb->stream, d, vb->pts, vb->cst, vb->acc1, vb->sh,
+                       vb->acc_x, vb->hx);
+    BP_TRY(hipGetLastError());
+    vb->collect_pending = true;
+    vb->stage = 2;
+    vb->begun_complete = false;
+    return BP_OK;
+  }
+  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow, true);
+  hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   prof_begin(vb, 0, vb->nt1);
   launch_fixed(vb, B * lpp, vb->nt1, lpp, vb->dig1, vb->tb1, vb->acc1);
   prof_end(vb, 0);
   // A device-to-host copy command after the kernel would serialise the chunks' streams against each
   // other (measured: benchmarks/concurrency_test3.hip); with pinned outputs the kernel stores its
   // result to host memory itself.
-  uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
-  if (vb->split) {
-    // the shifted forms come from the side stream (launched at prepare, ~0.6 ms of doublings): host-side join,
-    // which also covers the rounds' needs
-    if (vb->tab_pending && vb->aux != vb->stream) BP_TRY(hipStreamSynchronize(vb->aux));
-    vb->tab_pending = false;
-    hipLaunchKernelGGL(k_stage1_tail_split, dim3(d.B), dim3(64), 0, vb->stream, d, vb->pts, vb->cst, vb->acc1,
-                       vb->rsh + (size_t)2 * d.k * B * SPLIT_S, vb->rsplit_tab, vb->acc_aff, direct,
-                       vb->direct_host ? out_text : nullptr);
-  } else {
-    hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
-                       vb->direct_host ? out_text : nullptr);
-  }
+  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
+                     vb->direct_host ? out_text : nullptr);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
@@ -919,10 +985,21 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   // The two inversions of a round are per lane: the kernel is a latency chain the host waits for, and sharing
   // them across the workgroup (batchinv.h) lengthens it (1.58 -> 1.71 ms).  BP_ROUND_BATCHINV=1 selects the shared form.
   static const bool round_batch = getenv("BP_ROUND_BATCHINV") && atoi(getenv("BP_ROUND_BATCHINV")) != 0;
-  if (vb->split)
-    hipLaunchKernelGGL(k_round_split, dim3(d.B), dim3(64), 0, vb->stream, d, round, xin, vb->xk_m, vb->xkinv_m, vb->rsh,
-                       vb->rsplit_tab, vb->acc_aff, direct, vb->direct_host ? out_text : nullptr);
-  else if (round_batch)
+  if (vb->split) {
+    for (size_t p = 0; p < B; p++) {  // x_r^-1 on the host (`x` is host memory in both modes)
+      u256 xv;
+      memcpy(&xv, x + p * 32, 32);
+      xv = Fr::inv(Fr::to_mont(Fr::reduce_once(xv)));
+      memcpy(vb->hinv + ((size_t)HI_XINV * B + p) * 32, &xv, 32);
+    }
+    hipLaunchKernelGGL(k_round_bits, dim3(d.B), dim3(256), 0, vb->stream, d, round, xin, vb->hinv, vb->xk_m, vb->xkinv_m,
+                       vb->sh, vb->acc_x, vb->hx);
+    BP_TRY(hipGetLastError());
+    vb->collect_pending = true;
+    vb->stage++;
+    return BP_OK;
+  }
+  if (round_batch)
     hipLaunchKernelGGL(k_round<true>, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct,
                        vb->direct_host ? out_text : nullptr);
   else
@@ -957,7 +1034,8 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
     launch_tcheck(vb, vb->stream);
   }
   uint8_t* direct = vb->direct_host ? verdicts : nullptr;
-  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->bad, vb->verdict, direct);
+  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, vb->split ? vb->acc_x : nullptr, vb->bad,
+                     vb->verdict, direct);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 1;  // may be begun again with the same loaded proofs
@@ -973,6 +1051,16 @@ int vbatch_join_side(bp_vbatch* vb) {
     if (vb->aux != vb->stream) BP_TRY(hipStreamSynchronize(vb->aux));
     vb->tab_pending = false;
   }
+  return BP_OK;
+}
+
+int vbatch_collect(bp_vbatch* vb, uint8_t* out_commitment) {
+  if (!vb->split || !vb->collect_pending) return BP_OK;
+  for (size_t p = 0; p < vb->d.B; p++) {
+    affine a = xyzz_to_affine(vb->hx[p]);
+    memcpy(out_commitment + p * 64, &a, 64);
+  }
+  vb->collect_pending = false;
   return BP_OK;
 }
 
@@ -1063,9 +1151,9 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->rtab = c.take<uint8_t>((size_t)15 * (d.k ? d.k : 1) * B * 64);
     {
       const size_t sb = B <= VSPLIT_MAX_B ? B : 1;
-      vb->rsh = c.take<xyzz>(((size_t)2 * (d.k ? d.k : 1) + 1) * sb * SPLIT_S);  // L_r, R_r rows, then S
-      vb->rsplit_tab = c.take<xyzz>(sb * 15 * 64);
-      vb->fpart = c.take<xyzz>(sb * ((vb->nt3a + 255) / 256));
+      vb->sh = c.take<xyzz>((size_t)(vb->npts - VP_S) * sb * GLV_LANE_BITS);  // bit tables of rows S.. (16 KB a point)
+      vb->acc_x = c.take<xyzz>(sb);
+      vb->fpart = c.take<xyzz>(sb * 64);
     }
     return c.off;
   };
@@ -1085,7 +1173,19 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][0]);
     if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][1]);
   }
+  vb->hx = nullptr;
+  vb->hinv = nullptr;
+  vb->collect_pending = false;
+  if (e == hipSuccess && vb->split) {  // pinned: [B] xyzz, then the host's inverses [3][B][32]
+    void* hp = nullptr;
+    e = hipHostMalloc(&hp, B * sizeof(xyzz) + 3 * B * 32, hipHostMallocDefault);
+    if (e == hipSuccess) {
+      vb->hx = (xyzz*)hp;
+      vb->hinv = (uint8_t*)hp + B * sizeof(xyzz);
+    }
+  }
   if (e != hipSuccess || vb->buf.reserve(need) != 0) {
+    if (vb->hx) (void)hipHostFree(vb->hx);
     delete vb;
     ctx->err = "verifier workspace allocation failed";
     return BP_ERR_NOMEM;
@@ -1111,6 +1211,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   if (e == hipSuccess) e = hipStreamSynchronize(vb->stream);
   if (e != hipSuccess) {
     vb->buf.release();
+    if (vb->hx) (void)hipHostFree(vb->hx);
     delete vb;
     ctx->err = std::string("bp_vbatch_create: ") + hipGetErrorString(e);
     return BP_ERR_DEVICE;
@@ -1128,6 +1229,7 @@ void bp_vbatch_destroy(bp_vbatch* vb) {
   (void)hipStreamSynchronize(vb->stream);
   if (vb->t_pending || vb->tab_pending) (void)hipStreamSynchronize(vb->aux);
   vb->buf.release();
+  if (vb->hx) (void)hipHostFree(vb->hx);
   for (int s = 0; s < 3; s++)
     for (int j = 0; j < 2; j++)
       if (vb->ev[s][j]) (void)hipEventDestroy(vb->ev[s][j]);
@@ -1153,7 +1255,8 @@ int bp_vbatch_begin(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commi
   BP_REQUIRE(challenges && out_commitment, "null pointer");
   BP_TRY(hipSetDevice(ctx->device));
   int rc = vbatch_begin_async(vb, challenges, out_commitment, nullptr, nullptr);
-  return rc != BP_OK ? rc : vbatch_wait(vb);
+  if (rc == BP_OK) rc = vbatch_wait(vb);
+  return rc != BP_OK ? rc : vbatch_collect(vb, out_commitment);
 }
 
 int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment) {
@@ -1162,7 +1265,8 @@ int bp_vbatch_round(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* ou
   BP_REQUIRE(x && out_commitment, "null pointer");
   BP_TRY(hipSetDevice(ctx->device));
   int rc = vbatch_round_async(vb, round, x, out_commitment, nullptr);
-  return rc != BP_OK ? rc : vbatch_wait(vb);
+  if (rc == BP_OK) rc = vbatch_wait(vb);
+  return rc != BP_OK ? rc : vbatch_collect(vb, out_commitment);
 }
 
 int bp_vbatch_finish(bp_vbatch* vb, uint8_t* verdicts) {
