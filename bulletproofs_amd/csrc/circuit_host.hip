@@ -11,6 +11,7 @@
 // tBlindings are explicit arguments in the reference's draw order.
 #include "prover.h"
 #include "fixedbase.h"
+#include "glv.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -540,6 +541,22 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
             t = fr_from_bytes(proof_scalars + 64), l = fr_from_bytes(proof_scalars + 96),
             r = fr_from_bytes(proof_scalars + 128);
 
+  // With the fixed-base tables every remaining variable-base term is one of the proof's own points (or gen, h, the
+  // commitments): their bit tables (ipp.hip) are built by one launch now, beside the host's vector algebra, and the
+  // short sums and the rounds of mkChallenges then run one lane per scalar bit.
+  // table order: AI, AO, S | T_1..T_7 | gen, h | V_0..V_{m-1} | L_0.. | R_0..
+  const bool fixed = prover_uses_fixed_base() && n2 > 0;
+  const uint32_t bt_T = 3, bt_G = 10, bt_V = 12, bt_L = 12 + m;
+  const bool bits = fixed && bt_L + 2 * k <= w.bit_cap;
+  if (bits) {
+    hipStream_t st = ctx->stream;
+    BP_TRY(hipMemcpyAsync(w.bit_pts, proof_points, (size_t)10 * 64, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(w.bit_pts + (size_t)bt_G * 64, g.gen_h, (size_t)2 * 64, hipMemcpyHostToDevice, st));
+    if (m) BP_TRY(hipMemcpyAsync(w.bit_pts + (size_t)bt_V * 64, v_commits, (size_t)m * 64, hipMemcpyHostToDevice, st));
+    if (k) BP_TRY(hipMemcpyAsync(w.bit_pts + (size_t)bt_L * 64, Lp, (size_t)2 * k * 64, hipMemcpyHostToDevice, st));
+    if ((rc = ipp_bit_tables(ctx, w.bit_pts, bt_L + 2 * k, w.bit_sh, st)) != BP_OK) return rc;
+  }
+
   // x, y, z   (Verifier.hs:28-30)
   uint8_t yb[32], zb[32], xb[32];
   challenge_x(style, T, xb);
@@ -554,7 +571,6 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   fr_to_bytes(t, canon3 + 64);
   challenge_u(style, canon3, ub);
   // with the fixed-base tables u = gen * ub and hs' = hs_i * y^-i never exist as points: both enter as scalar factors
-  const bool fixed = prover_uses_fixed_base() && n2 > 0;
   const Fr4 ubm = fr_from_bytes(ub);
   std::vector<uint32_t> tb_gh;  // gs_0.., hs_0.., h, gen
   if (fixed) {
@@ -573,6 +589,7 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   // verifyTPoly (:43-54): commit t tBlinding == gen*gExp + sumExps xs tCommits + sumExps vExp vCommits,
   // evaluated as one multiexp of the difference, which is O exactly when both sides are equal.
   bool t_ok;
+  xyzz bit_res[2];  // latency path: x*AI + x^2*AO + x^3*S, and the difference of verifyTPoly's two sides
   {
     Fr4 kdelta = zero, cQ = zero;  // delta n y zwL zwR (Internal.hs:99-100); cQ = zs . cs
     for (uint32_t i = 0; i < n2; i++) kdelta = fr_add(kdelta, fr_mul(fr_mul(d.yinv[i], d.zwR[i]), d.zwL[i]));
@@ -594,11 +611,30 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
         col = fr_add(col, fr_mul(d.zs[rr], fr_from_bytes(wV + ((size_t)rr * m + j) * 32)));
       sc.push_back(fr_neg(fr_mul(x2, col)));
     }
-    MsmSeg segs[3] = {{g.gen_h, 2, false}, {T, 7, false}, {v_commits, m, false}};
-    uint8_t diff[64];
-    if ((rc = msm_gather(ctx, w, segs, 3, sc, diff)) != BP_OK) return rc;
-    t_ok = true;
-    for (int i = 0; i < 64; i++) t_ok &= diff[i] == 0;
+    if (bits) {
+      // scalars in table order; the first three are those of x*AI + x^2*AO + x^3*S (verifyLRCommitment below): both
+      // sums leave in one launch
+      std::vector<uint8_t> sb((size_t)bt_L * 32);
+      fr_to_bytes(x, &sb[0]);
+      fr_to_bytes(x2, &sb[32]);
+      fr_to_bytes(x3, &sb[64]);
+      for (int i = 0; i < 7; i++) fr_to_bytes(sc[2 + i], &sb[(size_t)(bt_T + i) * 32]);
+      fr_to_bytes(sc[0], &sb[(size_t)bt_G * 32]);
+      fr_to_bytes(sc[1], &sb[(size_t)(bt_G + 1) * 32]);
+      for (uint32_t j = 0; j < m; j++) fr_to_bytes(sc[9 + j], &sb[(size_t)(bt_V + j) * 32]);
+      BP_TRY(hipMemcpyAsync(w.sc, sb.data(), sb.size(), hipMemcpyHostToDevice, ctx->stream));
+      const uint32_t first[2] = {0, bt_T}, count[2] = {3, 9 + m};
+      if ((rc = ipp_bits_multiexp(ctx, w.bit_sh, w.sc, first, count, 2, w.bit_out + 1)) != BP_OK) return rc;
+      BP_TRY(hipMemcpyAsync(bit_res, w.bit_out + 1, 2 * sizeof(xyzz), hipMemcpyDeviceToHost, ctx->stream));
+      BP_TRY(hipStreamSynchronize(ctx->stream));  // also releases w.sc for the sums below
+      t_ok = xyzz_is_inf(bit_res[1]);
+    } else {
+      MsmSeg segs[3] = {{g.gen_h, 2, false}, {T, 7, false}, {v_commits, m, false}};
+      uint8_t diff[64];
+      if ((rc = msm_gather(ctx, w, segs, 3, sc, diff)) != BP_OK) return rc;
+      t_ok = true;
+      for (int i = 0; i < 64; i++) t_ok &= diff[i] == 0;
+    }
   }
 
   // verifyLRCommitment (:56-71)
@@ -617,15 +653,22 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
     const std::vector<Fr4>* scs[1] = {&sc};
     uint8_t* outs[1] = {fpart};
     if ((rc = fb_msm_host(ctx, w, tb_gh, 1, scs, outs)) != BP_OK) return rc;
-    uint8_t three[3 * 64];
-    memcpy(three, AI, 64);
-    memcpy(three + 64, AO, 64);
-    memcpy(three + 128, S, 64);
-    std::vector<Fr4> sv{x, x2, x3};
-    MsmSeg segs[1] = {{three, 3, false}};
-    MsmJob vjobs[1] = {{segs, 1, &sv, vpart}};
-    if ((rc = msm_multi(ctx, w, vjobs, 1)) != BP_OK) return rc;
-    if ((rc = bp_point_add(ctx, fpart, vpart, 1, acc)) != BP_OK) return rc;
+    if (bits) {
+      affine fa;
+      memcpy(&fa, fpart, 64);
+      affine sum = xyzz_to_affine(xyzz_madd(bit_res[0], fa));  // on the host: microseconds
+      memcpy(acc, &sum, 64);
+    } else {
+      uint8_t three[3 * 64];
+      memcpy(three, AI, 64);
+      memcpy(three + 64, AO, 64);
+      memcpy(three + 128, S, 64);
+      std::vector<Fr4> sv{x, x2, x3};
+      MsmSeg segs[1] = {{three, 3, false}};
+      MsmJob vjobs[1] = {{segs, 1, &sv, vpart}};
+      if ((rc = msm_multi(ctx, w, vjobs, 1)) != BP_OK) return rc;
+      if ((rc = bp_point_add(ctx, fpart, vpart, 1, acc)) != BP_OK) return rc;
+    }
   } else {
     if ((rc = load_ipp_base(ctx, w, g, d.yinv, n2)) != BP_OK) return rc;
     // commitmentLR = x*AI + x^2*AO + x^3*S + sumExps gExp gs + sumExps hExp hs' - mu*h + t*u
@@ -651,7 +694,9 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   // IPP.verifyProof n (gs, hs', u) commitmentLR productProof   (InnerProductProof/Verifier.hs:18-38)
   // mkChallenges (:40-53): x_j = shamirX' acc L_j R_j; acc <- x_j^2 L_j + x_j^-2 R_j + acc
   std::vector<Fr4> chal;  // round order; the reference's list is this reversed
-  if ((rc = mk_challenges_dev(ctx, w, style, acc, Lp, Rp, k, chal)) != BP_OK) return rc;
+  if ((rc = mk_challenges_dev(ctx, w, style, acc, Lp, Rp, k, chal,
+                              bits && k ? w.bit_sh + (size_t)bt_L * GLV_LANE_BITS : nullptr)) != BP_OK)
+    return rc;
   // mkOtherExponents (:55-73): s_0 = (prod x)^-1, s_{i + 2^j} = s_i * c_j^2 with c_0 the LAST round's challenge
   bool lr_ok;
   {

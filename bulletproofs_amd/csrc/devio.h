@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ec.h"
+#include "glv.h"
 
 namespace bp {
 
@@ -76,6 +77,13 @@ __device__ __forceinline__ xyzz wave_sum_width(xyzz v, int width) {
   }
   return v;
 }
+// This lane's term of k * point (k canonical, < r) from the point's bit table tab[j] = 2^j * point (glv.h glv_bit_lane)
+__device__ __forceinline__ xyzz bit_lane_term(const u256& k, const xyzz* __restrict__ tab, int j) {
+  GlvHalf h1, h2;
+  glv_split(k, h1, h2);
+  return glv_bit_lane(h1, h2, ld_xyzz(&tab[j]), j);
+}
+
 // Sum over a workgroup of up to 1024 threads; thread 0 holds the result.
 // `lds` must hold blockDim.x/64 xyzz values.
 __device__ __forceinline__ xyzz block_sum(xyzz v, xyzz* lds) {

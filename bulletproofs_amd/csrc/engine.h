@@ -144,11 +144,15 @@ int msm_direct_multi(bp_ctx* ctx, const uint8_t* d_scalars, const uint8_t* d_poi
 size_t msm_direct_limit();
 int ipp_fold_points(bp_ctx* ctx, const uint8_t* d_lo, const uint8_t* d_hi, uint32_t n, const uint8_t s_lo[32],
                     const uint8_t s_hi[32], xyzz* d_tab, uint8_t* d_out);
-// the same through 8 lanes: d_sh = 2^(17 s) * p for s < 8 (ipp_shift_points, once per point), d_tab: 15 x 64 xyzz
-constexpr int IPP_SPLIT_S = 8;
-int ipp_shift_points(bp_ctx* ctx, const uint8_t* d_pts, uint32_t n, xyzz* d_sh);
-int ipp_lincomb2_add_split(bp_ctx* ctx, const xyzz* d_sh0, const xyzz* d_sh1, const uint8_t* d_p2, const uint8_t k0[32],
-                           const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out);
+// The latency path's short sums (ipp.hip): bit tables d_sh[point][128] = 2^j * point (16 KB a point), then one lane
+// per scalar bit.  ipp_bits_lincomb2: *d_acc <- k0*p0 + k1*p1 + *d_acc (XYZZ, stays on the device);
+// ipp_bits_multiexp: d_out[b] = sum over the tables first[b] .. first[b] + count[b] with the scalars (canonical,
+// 32 B, device) of the same indices, up to four sums in one launch.
+int ipp_bit_tables(bp_ctx* ctx, const uint8_t* d_pts, uint32_t n, xyzz* d_sh, hipStream_t st);
+int ipp_bits_lincomb2(bp_ctx* ctx, const xyzz* d_sh0, const xyzz* d_sh1, const uint8_t k0[32], const uint8_t k1[32],
+                      xyzz* d_acc);
+int ipp_bits_multiexp(bp_ctx* ctx, const xyzz* d_sh, const uint8_t* d_scalars, const uint32_t* first, const uint32_t* count,
+                      int nsums, xyzz* d_out);
 int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, const uint8_t* d_p2, const uint8_t k0[32],
                      const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out);
 int ipp_scale_points(bp_ctx* ctx, const uint8_t* d_pts, const uint8_t* d_scalars, uint32_t n, xyzz* d_tab,

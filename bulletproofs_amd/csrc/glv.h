@@ -205,11 +205,7 @@ BP_HD xyzz glv_pair_multiexp_tab(const u256& k0, const u256& k1, LoadAff load) {
   return acc;
 }
 
-// ---- one k0*p0 + k1*p1 spread over SPLIT_S lanes --------------------------------------------------------
-// Lane s handles bits [SPLIT_W s, SPLIT_W s + SPLIT_W) of the four signed GLV halves on the points shifted by
-// 2^(SPLIT_W s) (P0s = 2^(SPLIT_W s) p0, P1s likewise, XYZZ): SPLIT_W doublings and additions instead of 129.
-// The lanes' results add up to k0*p0 + k1*p1.  store/load: this lane's 15 joint-table slots.
-constexpr int SPLIT_S = 8, SPLIT_W = 17;  // 8 x 17 = 136 >= GLV_BITS
+// bit i of a 129-bit magnitude
 BP_HD uint32_t mag_bit(const uint32_t (&m)[5], int i) {
   const int w = i >> 5;
   uint32_t v = m[0];
@@ -225,34 +221,6 @@ BP_HD xyzz xyzz_phi(const xyzz& p) {  // (beta X, Y, ZZ, ZZZ); the identity stay
   r.X = fq_mul(p.X, glv_const(BETA));
   return r;
 }
-template <class Store, class Load>
-BP_HD xyzz glv_split_lane(const u256& k0, const u256& k1, const xyzz& P0s, const xyzz& P1s, int s, Store store, Load load) {
-  GlvHalf a1, a2, b1, b2;
-  glv_split(k0, a1, a2);
-  glv_split(k1, b1, b2);
-  xyzz Q0 = xyzz_phi(P0s), Q1 = xyzz_phi(P1s);
-  store(1, a1.neg ? xyzz_neg(P0s) : P0s);
-  store(2, a2.neg ? xyzz_neg(Q0) : Q0);
-  store(4, b1.neg ? xyzz_neg(P1s) : P1s);
-  store(8, b2.neg ? xyzz_neg(Q1) : Q1);
-#pragma unroll 1
-  for (int e = 3; e < 16; e++) {
-    int top = 31 - __builtin_clz((unsigned)e);
-    int rest = e & ~(1 << top);
-    if (rest == 0) continue;
-    store(e, xyzz_add(load(rest), load(1 << top)));
-  }
-  xyzz acc = xyzz_inf();
-#pragma unroll 1
-  for (int b = SPLIT_W - 1; b >= 0; b--) {
-    const int pos = SPLIT_W * s + b;
-    uint32_t idx = mag_bit(a1.m, pos) | (mag_bit(a2.m, pos) << 1) | (mag_bit(b1.m, pos) << 2) | (mag_bit(b2.m, pos) << 3);
-    acc = xyzz_dbl(acc);
-    if (idx) acc = xyzz_add(acc, load((int)idx));
-  }
-  return acc;
-}
-
 // ---- k*P with one lane per bit -------------------------------------------------------------------------------
 // Lane j < GLV_LANE_BITS holds Tj = 2^j P (XYZZ) and contributes [bit j of |k1|] (+-Tj) + [bit j of |k2|] (+-phi(Tj)),
 // k = k1 + k2*lambda the signed split: no doubling and at most one addition per lane, and the lanes' terms add up

@@ -59,42 +59,53 @@ __global__ void __launch_bounds__(64) k_lincomb2_add(const uint8_t* __restrict__
   st_affine(out, xyzz_to_affine(acc));
 }
 
-// ---- the same group element with the 129 steps spread over SPLIT_S lanes ---------------------------------
-// A single proof's verifier walks one k0*p0 + k1*p1 + p2 per round (mkChallenges,
-// InnerProductProof/Verifier.hs:47-50), a 129-step double-and-add chain that one lane runs in ~1.5 ms while the
-// rest of the GPU idles.  p0, p1 (the proof's L_j, R_j) are known before any challenge: k_shift_points computes
-// 2^(SPLIT_W s) * p for s < SPLIT_S once for all rounds, and lane s of k_lincomb2_add_split then handles bits
-// [SPLIT_W s, SPLIT_W s + SPLIT_W) of the four GLV halves on the points shifted by 2^(SPLIT_W s): 17 steps per
-// lane, a shuffle sum over the lanes, one normalisation.  Exact: the lanes' partial sums add up to the same element.
-__global__ void __launch_bounds__(64) k_shift_points(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][SPLIT_S]*/) {
+// ---- short multi-exponentiations on the latency path: one lane per scalar bit ---------------------------------
+// A single proof's verifier walks one k0*p0 + k1*p1 + acc per round (mkChallenges,
+// InnerProductProof/Verifier.hs:47-50) and a few short sums over the proof's own points, 129-step double-and-add
+// chains that one lane runs in ~1.5 ms while the rest of the GPU idles.  The points are known before any
+// challenge: k_bit_tables writes 2^j * p, j < 128, once per point (one chain of doublings for all of them side by
+// side), and a product k * p is then one lane per bit (glv.h glv_bit_lane: at most one addition) and a
+// workgroup sum.  Exact: the lanes' terms add up to the same group element.
+__global__ void __launch_bounds__(64) k_bit_tables(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][128]*/) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   xyzz a = xyzz_from_affine(ld_affine(pts + (size_t)i * 64));
-  st_xyzz(&sh[(size_t)i * SPLIT_S], a);
+  st_xyzz(&sh[(size_t)i * GLV_LANE_BITS], a);
 #pragma unroll 1
-  for (int s = 1; s < SPLIT_S; s++) {
-#pragma unroll 1
-    for (int b = 0; b < SPLIT_W; b++) a = xyzz_dbl(a);
-    st_xyzz(&sh[(size_t)i * SPLIT_S + s], a);
+  for (int j = 1; j < GLV_LANE_BITS; j++) {
+    a = xyzz_dbl(a);
+    st_xyzz(&sh[(size_t)i * GLV_LANE_BITS + j], a);
   }
 }
 
-// out = k0*p0 + k1*p1 + p2 from the shifted forms sh0, sh1 ([SPLIT_S] each) of p0, p1; one wave, tab: 15 x 64 xyzz
-__global__ void __launch_bounds__(64) k_lincomb2_add_split(const xyzz* __restrict__ sh0, const xyzz* __restrict__ sh1,
-                                                          const uint8_t* __restrict__ p2, u256 k0, u256 k1,
-                                                          xyzz* __restrict__ tab, uint8_t* __restrict__ out) {
-  const int s = threadIdx.x;
+// acc <- k0*p0 + k1*p1 + acc, p0 / p1 by their bit tables; 256 lanes, the result stays XYZZ (the host normalises)
+__global__ void __launch_bounds__(256) k_bits_lincomb2(const xyzz* __restrict__ sh0, const xyzz* __restrict__ sh1, u256 k0,
+                                                      u256 k1, xyzz* __restrict__ acc) {
+  __shared__ xyzz red[4];
+  const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
+  xyzz term = bit_lane_term(side ? k1 : k0, side ? sh1 : sh0, j);
+  xyzz sum = block_sum(term, red);
+  if (t == 0) st_xyzz(acc, xyzz_add(sum, ld_xyzz(acc)));
+}
+
+// out[b] = sum_t scalars[first_b + t] * point(first_b + t), t < count_b, for up to four sums b = blockIdx.x over
+// consecutive tables; two terms per pass over the bit positions, one workgroup sum at the end
+struct BitSums {
+  uint32_t first[4], count[4];
+};
+__global__ void __launch_bounds__(256) k_bits_multiexp(const xyzz* __restrict__ sh, const uint8_t* __restrict__ scalars,
+                                                      BitSums bs, xyzz* __restrict__ out) {
+  __shared__ xyzz red[4];
+  const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
+  const uint32_t first = bs.first[blockIdx.x], count = bs.count[blockIdx.x];
   xyzz acc = xyzz_inf();
-  if (s < SPLIT_S) {
-    auto store = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * 64 + s], v); };
-    auto load = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * 64 + s]); };
-    acc = glv_split_lane(k0, k1, ld_xyzz(&sh0[s]), ld_xyzz(&sh1[s]), s, store, load);
+#pragma unroll 1
+  for (uint32_t term = (uint32_t)side; term < count; term += 2) {
+    u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)(first + term) * 32));
+    acc = xyzz_add(acc, bit_lane_term(k, sh + (size_t)(first + term) * GLV_LANE_BITS, j));
   }
-  acc = wave_sum(acc);  // lanes >= SPLIT_S hold the identity
-  if (s == 0) {
-    acc = xyzz_madd(acc, ld_affine(p2));
-    st_affine(out, xyzz_to_affine(acc));
-  }
+  xyzz sum = block_sum(acc, red);
+  if (t == 0) st_xyzz(&out[blockIdx.x], sum);
 }
 
 // out[i] = scalars[i] * pts[i], independent scalars (canonical, 32 B each): GLV, one lane per i
@@ -182,18 +193,35 @@ int ipp_lincomb2_add(bp_ctx* ctx, const uint8_t* d_p0, const uint8_t* d_p1, cons
   return BP_OK;
 }
 
-int ipp_shift_points(bp_ctx* ctx, const uint8_t* d_pts, uint32_t n, xyzz* d_sh) {
-  hipLaunchKernelGGL(k_shift_points, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_pts, n, d_sh);
+int ipp_bit_tables(bp_ctx* ctx, const uint8_t* d_pts, uint32_t n, xyzz* d_sh, hipStream_t st) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(k_bit_tables, dim3((n + 63) / 64), dim3(64), 0, st, d_pts, n, d_sh);
   BP_TRY(hipGetLastError());
   return BP_OK;
 }
 
-int ipp_lincomb2_add_split(bp_ctx* ctx, const xyzz* d_sh0, const xyzz* d_sh1, const uint8_t* d_p2, const uint8_t k0[32],
-                           const uint8_t k1[32], xyzz* d_tab, uint8_t* d_out) {
+int ipp_bits_lincomb2(bp_ctx* ctx, const xyzz* d_sh0, const xyzz* d_sh1, const uint8_t k0[32], const uint8_t k1[32],
+                      xyzz* d_acc) {
   u256 a, b;
   memcpy(a.v, k0, 32);
   memcpy(b.v, k1, 32);
-  hipLaunchKernelGGL(k_lincomb2_add_split, dim3(1), dim3(64), 0, ctx->stream, d_sh0, d_sh1, d_p2, a, b, d_tab, d_out);
+  hipLaunchKernelGGL(k_bits_lincomb2, dim3(1), dim3(256), 0, ctx->stream, d_sh0, d_sh1, a, b, d_acc);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
+int ipp_bits_multiexp(bp_ctx* ctx, const xyzz* d_sh, const uint8_t* d_scalars, const uint32_t* first, const uint32_t* count,
+                      int nsums, xyzz* d_out) {
+  if (nsums < 1 || nsums > 4) {
+    ctx->err = "ipp_bits_multiexp: one to four sums";
+    return BP_ERR_ARG;
+  }
+  BitSums bs;
+  for (int i = 0; i < 4; i++) {
+    bs.first[i] = i < nsums ? first[i] : 0;
+    bs.count[i] = i < nsums ? count[i] : 0;
+  }
+  hipLaunchKernelGGL(k_bits_multiexp, dim3(nsums), dim3(256), 0, ctx->stream, d_sh, d_scalars, bs, d_out);
   BP_TRY(hipGetLastError());
   return BP_OK;
 }

@@ -28,9 +28,12 @@ struct ProverWs {
   uint8_t* sc;       // MSM scalars, same layout
   uint8_t* small;    // 16 single points: u, P, L, R, ...; slots 12..15 = MSM outputs
   xyzz* tab;         // 15 * (n + 2) joint-table scratch
-  xyzz* split_tab;   // 15 x 64 joint tables of the lane-split round kernel (ipp.hip)
-  xyzz* split_sh;    // shifted forms of up to 32 points (L_j, R_j of a proof), 8 each
-  uint8_t* split_pts;  // those points, affine
+  // the latency path's short sums (ipp.hip, ipp_bit_tables): up to bit_cap points of a proof, affine, their bit
+  // tables (16 KB a point) and a few XYZZ results
+  uint32_t bit_cap;
+  uint8_t* bit_pts;
+  xyzz* bit_sh;
+  xyzz* bit_out;  // 8 entries; entry 0 is the running commitment of mk_challenges_dev
   FrDev fr;            // scalar-field vectors (frvec.hip)
 };
 
@@ -91,9 +94,10 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
 // mkChallenges (InnerProductProof/Verifier.hs:40-53): x_j = shamirX' acc L_j R_j; acc <- x_j^2 L_j + x_j^-2 R_j + acc for
 // j < k.  acc: commitmentLR in, the final accumulator out (host bytes); Lp, Rp: k points each (host); chal: the
 // challenges in ROUND order (the reference's list is this reversed).  Hashing on the host, the group work on the GPU
-// (eight lanes per round on shifted forms of L_j, R_j when 2k <= 32).
+// (one lane per scalar bit on the bit tables of L_j, R_j, ipp.hip; the host normalises the running commitment).
+// d_sh_lr: bit tables of L_0..L_{k-1}, R_0..R_{k-1} the caller has built already (ipp_bit_tables), or null.
 int mk_challenges_dev(bp_ctx* ctx, ProverWs& w, host::ShowStyle style, uint8_t acc[64], const uint8_t* Lp,
-                      const uint8_t* Rp, uint32_t k, std::vector<host::Fr4>& chal);
+                      const uint8_t* Rp, uint32_t k, std::vector<host::Fr4>& chal, const xyzz* d_sh_lr = nullptr);
 // BP_PROVER_HOSTVEC=1 keeps the provers' scalar-field vector work on the host (the round-1 path; A/B timing)
 bool prover_vectors_on_device();
 // BP_PROVER_FOLD=1 keeps the provers on ipp_prove_core (device-side generator folds)

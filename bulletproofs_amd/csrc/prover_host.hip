@@ -10,6 +10,7 @@
 // t2Blinding from MonadRandom in that order; here they are explicit arguments.
 #include "prover.h"
 #include "fixedbase.h"
+#include "glv.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -28,9 +29,10 @@ int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra) {
     w.sc = c.take<uint8_t>(4 * w.seg_cap * 32);
     w.small = c.take<uint8_t>(16 * 64);
     w.tab = c.take<xyzz>((size_t)15 * (n + 2));
-    w.split_tab = c.take<xyzz>((size_t)15 * 64);
-    w.split_sh = c.take<xyzz>((size_t)32 * IPP_SPLIT_S);
-    w.split_pts = c.take<uint8_t>((size_t)32 * 64);
+    w.bit_cap = 64 + extra;
+    w.bit_pts = c.take<uint8_t>((size_t)w.bit_cap * 64);
+    w.bit_sh = c.take<xyzz>((size_t)w.bit_cap * GLV_LANE_BITS);
+    w.bit_out = c.take<xyzz>(8);
     w.fr.cap = n;
     w.fr.ls = c.take<u256>(n);
     w.fr.rs = c.take<u256>(n);
@@ -429,23 +431,51 @@ int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<Fr4>
 }
 
 int mk_challenges_dev(bp_ctx* ctx, ProverWs& w, ShowStyle style, uint8_t acc[64], const uint8_t* Lp, const uint8_t* Rp,
-                      uint32_t k, std::vector<Fr4>& chal) {
+                      uint32_t k, std::vector<Fr4>& chal, const xyzz* d_sh_lr) {
   hipStream_t st = ctx->stream;
   int rc;
   chal.assign(k, fr_zero());
   if (k == 0) return BP_OK;
+  // The proof's L_j, R_j are known up front: with their bit tables a round is one short launch, the running
+  // commitment stays XYZZ on the device, and the host normalises its copy between the hashes.
+  const bool bits = d_sh_lr || (prover_uses_fixed_base() && 2 * k <= w.bit_cap);
+  if (bits) {
+    if (!d_sh_lr) {
+      BP_TRY(hipMemcpyAsync(w.bit_pts, Lp, (size_t)k * 64, hipMemcpyHostToDevice, st));
+      BP_TRY(hipMemcpyAsync(w.bit_pts + (size_t)k * 64, Rp, (size_t)k * 64, hipMemcpyHostToDevice, st));
+      if ((rc = ipp_bit_tables(ctx, w.bit_pts, 2 * k, w.bit_sh, st)) != BP_OK) return rc;
+      d_sh_lr = w.bit_sh;
+    }
+    affine a0;
+    memcpy(&a0, acc, 64);
+    xyzz ax = xyzz_from_affine(a0);
+    BP_TRY(hipMemcpyAsync(w.bit_out, &ax, sizeof(xyzz), hipMemcpyHostToDevice, st));
+    for (uint32_t j = 0; j < k; j++) {
+      uint8_t buf[MSG_SCRATCH], xjb[32], x2b[32], xi2b[32];
+      Msg mm(buf, style);
+      mm.r();
+      mm.point(Lp + (size_t)j * 64);
+      mm.point(Rp + (size_t)j * 64);
+      mm.point(acc);
+      mm.finish_fr(xjb);
+      chal[j] = fr_from_bytes(xjb);
+      fr_to_bytes(fr_sqr(chal[j]), x2b);
+      fr_to_bytes(fr_sqr(fr_inv(chal[j])), xi2b);
+      if ((rc = ipp_bits_lincomb2(ctx, d_sh_lr + (size_t)j * GLV_LANE_BITS, d_sh_lr + (size_t)(k + j) * GLV_LANE_BITS, x2b,
+                                  xi2b, w.bit_out)) != BP_OK)
+        return rc;
+      BP_TRY(hipMemcpyAsync(&ax, w.bit_out, sizeof(xyzz), hipMemcpyDeviceToHost, st));
+      BP_TRY(hipStreamSynchronize(st));
+      affine an = xyzz_to_affine(ax);
+      memcpy(acc, &an, 64);
+    }
+    return BP_OK;
+  }
   uint8_t* d_acc = w.small + 64;
   uint8_t* d_L = w.small + 128;
   uint8_t* d_R = w.small + 192;
   uint8_t* d_new = w.small + 256;
   BP_TRY(hipMemcpyAsync(d_acc, acc, 64, hipMemcpyHostToDevice, st));
-  // the proof's L_j, R_j are known up front: their shifted forms let eight lanes share each round's chain
-  const bool split = prover_uses_fixed_base() && 2 * k <= 32;
-  if (split) {
-    BP_TRY(hipMemcpyAsync(w.split_pts, Lp, (size_t)k * 64, hipMemcpyHostToDevice, st));
-    BP_TRY(hipMemcpyAsync(w.split_pts + (size_t)k * 64, Rp, (size_t)k * 64, hipMemcpyHostToDevice, st));
-    if ((rc = ipp_shift_points(ctx, w.split_pts, 2 * k, w.split_sh)) != BP_OK) return rc;
-  }
   for (uint32_t j = 0; j < k; j++) {
     const uint8_t* Lj = Lp + (size_t)j * 64;
     const uint8_t* Rj = Rp + (size_t)j * 64;
@@ -459,15 +489,9 @@ int mk_challenges_dev(bp_ctx* ctx, ProverWs& w, ShowStyle style, uint8_t acc[64]
     chal[j] = fr_from_bytes(xjb);
     fr_to_bytes(fr_sqr(chal[j]), x2b);
     fr_to_bytes(fr_sqr(fr_inv(chal[j])), xi2b);
-    if (split) {
-      if ((rc = ipp_lincomb2_add_split(ctx, w.split_sh + (size_t)j * IPP_SPLIT_S, w.split_sh + (size_t)(k + j) * IPP_SPLIT_S,
-                                       d_acc, x2b, xi2b, w.split_tab, d_new)) != BP_OK)
-        return rc;
-    } else {
-      BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
-      BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
-      if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
-    }
+    BP_TRY(hipMemcpyAsync(d_L, Lj, 64, hipMemcpyHostToDevice, st));
+    BP_TRY(hipMemcpyAsync(d_R, Rj, 64, hipMemcpyHostToDevice, st));
+    if ((rc = ipp_lincomb2_add(ctx, d_L, d_R, d_acc, x2b, xi2b, w.tab, d_new)) != BP_OK) return rc;
     BP_TRY(hipMemcpyAsync(acc, d_new, 64, hipMemcpyDeviceToHost, st));
     BP_TRY(hipMemcpyAsync(d_acc, d_new, 64, hipMemcpyDeviceToDevice, st));
     BP_TRY(hipStreamSynchronize(st));

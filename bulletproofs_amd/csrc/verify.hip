@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 // ---- small batches: the latency path ------------------------------------------------------------------------
 // With a handful of proofs the 129-step chains of k_round / k_stage1_tail / k_var_terms leave the GPU idle and set
 // the latency of a verification.  Every point of a proof (S, T1, T2, L_r, R_r, V_j) is known before any challenge:
-// k_vshift_bits writes 2^j * point for j < 128 once per pass (side stream, beside the host's first hashes), and a
+// ipp.hip's k_bit_tables writes 2^j * point for j < 128 once per pass (side stream, beside the host's first hashes), and a
 // product k * point is then one lane per bit (glv.h, glv_bit_lane: at most one addition) and a workgroup sum.
 // The field inversions of the path (y^-1, (y - 1)^-1, x_r^-1, and the normalisation of each running commitment)
 // are done by the host between its hashes, microseconds each against ~0.14 ms for one lane of the GPU.
@@ -497,25 +497,6 @@ enum { HI_YINV = 0, HI_YM1INV = 1, HI_XINV = 2 };
 
 // bit-table index of row `row` (>= VP_S) of proof p
 __device__ __forceinline__ size_t sh_index(uint32_t row, size_t B, uint32_t p) { return ((size_t)(row - VP_S) * B + p) * GLV_LANE_BITS; }
-
-__global__ void __launch_bounds__(64) k_vshift_bits(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][128]*/) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  xyzz a = xyzz_from_affine(ld_affine(pts + (size_t)i * 64));
-  st_xyzz(&sh[(size_t)i * GLV_LANE_BITS], a);
-#pragma unroll 1
-  for (int j = 1; j < GLV_LANE_BITS; j++) {
-    a = xyzz_dbl(a);
-    st_xyzz(&sh[(size_t)i * GLV_LANE_BITS + j], a);
-  }
-}
-
-// this lane's term of k * point (k canonical), the point given by its bit table
-__device__ __forceinline__ xyzz bit_lane_term(const u256& k, const xyzz* __restrict__ tab, int j) {
-  GlvHalf h1, h2;
-  glv_split(k, h1, h2);
-  return glv_bit_lane(h1, h2, ld_xyzz(&tab[j]), j);
-}
 
 // thread per proof: k_vprep0 with the host's inversions (hinv) and the closed-form power sum
 __global__ void __launch_bounds__(64) k_vprep0_split(VDims d, const uint8_t* __restrict__ chal /*[4][B][32]*/,
@@ -871,7 +852,8 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
   if (vb->split) {
     // every row from S on; the host formats L_r, R_r itself on this path (no text kernel)
     const uint32_t cnt = (vb->npts - VP_S) * d.B;
-    hipLaunchKernelGGL(k_vshift_bits, dim3((cnt + 63) / 64), dim3(64), 0, vb->aux, vb->pts + (size_t)VP_S * B * 64, cnt, vb->sh);
+    int rc = ipp_bit_tables(ctx, vb->pts + (size_t)VP_S * B * 64, cnt, vb->sh, vb->aux);
+    if (rc != BP_OK) return rc;
   } else {
     if (lr_text && vb->direct_host) {
       size_t cnt = (size_t)2 * d.k * B * 2;

@@ -145,6 +145,18 @@ extern "C" void hs_glv_pair_tab(const uint8_t* ks, const uint8_t* ps, uint8_t* o
   sta(out, xyzz_to_affine(r));
 }
 
+// k*P as the verifier's latency path forms it: the bit table 2^j P, one glv_bit_lane term per j, summed
+extern "C" void hs_glv_bit_lanes(const uint8_t* k, const uint8_t* pt, uint8_t* out) {
+  GlvHalf h1, h2;
+  glv_split(ld(k), h1, h2);
+  xyzz t = xyzz_from_affine(lda(pt)), acc = xyzz_inf();
+  for (int j = 0; j < GLV_LANE_BITS; j++) {
+    acc = xyzz_add(acc, glv_bit_lane(h1, h2, t, j));
+    t = xyzz_dbl(t);
+  }
+  sta(out, xyzz_to_affine(acc));
+}
+
 // ---- device decimal formatter (dec.h): 80-byte record of a 32-byte LE integer ----
 #include "../../bulletproofs_amd/csrc/dec.h"
 extern "C" void hs_dec_record(const uint8_t* le, uint8_t* rec80) {

@@ -176,6 +176,22 @@ def test_glv_positive_split_and_pair_table(hs):
             assert dp(out.raw) == o.add_two_mul_p(k0, p0, k1, p1)
 
 
+def test_glv_bit_lanes(hs):
+    """glv.h glv_bit_lane (the verifier's latency path, verify.hip k_round_bits / k_tcheck_bits): the 128 per-bit terms
+    on the table 2^j P add up to k*P, for edge scalars, the identity and both signs of the halves."""
+    rng = random.Random(78)
+    A = o.point_mul(o.GEN, rng.randrange(1, R))
+    ks = [0, 1, 2, R - 1, R - 2, LAMBDA, R - LAMBDA, (R - 1) // 2, (R + 1) // 2, 2**127, 2**128, 2**255] + \
+         [rng.randrange(R) for _ in range(40)]
+    for k in ks:
+        out = ctypes.create_string_buffer(64)
+        hs.hs_glv_bit_lanes(b(k), pb(A), out)
+        assert dp(out.raw) == o.point_mul(A, k)
+    out = ctypes.create_string_buffer(64)
+    hs.hs_glv_bit_lanes(b(rng.randrange(R)), pb(None), out)
+    assert dp(out.raw) is None
+
+
 def msm(hs, es, ps, c):
     out = ctypes.create_string_buffer(64)
     hs.hs_msm(b"".join(b(e) for e in es), b"".join(pb(p) for p in ps), len(es), c, out)
