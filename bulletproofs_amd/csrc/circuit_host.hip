@@ -12,6 +12,7 @@
 #include "prover.h"
 #include "fixedbase.h"
 #include "glv.h"
+#include "host_inv.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -656,7 +657,7 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
     if (bits) {
       affine fa;
       memcpy(&fa, fpart, 64);
-      affine sum = xyzz_to_affine(xyzz_madd(bit_res[0], fa));  // on the host: microseconds
+      affine sum = host::xyzz_to_affine_host(xyzz_madd(bit_res[0], fa));  // on the host: microseconds
       memcpy(acc, &sum, 64);
     } else {
       uint8_t three[3 * 64];

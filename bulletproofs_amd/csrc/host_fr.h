@@ -121,16 +121,84 @@ static inline Fr4 fr_from_u64(uint64_t x) {
   memcpy(b, &x, 8);
   return fr_from_bytes(b);
 }
-// a^(r-2); inverse of 0 is 0
-static inline Fr4 fr_inv(const Fr4& a) {
-  static const uint64_t E[4] = {0xBFD25E8CD036413FULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL,
-                                0xFFFFFFFFFFFFFFFFULL};
-  Fr4 r = fr_one();
-  for (int i = 255; i >= 0; i--) {
-    r = fr_sqr(r);
-    if ((E[i >> 6] >> (i & 63)) & 1) r = fr_mul(r, a);
+// ---- modular inversion: binary extended Euclid on four 64-bit limbs (a few microseconds) ----------------------
+typedef unsigned __int128 inv_u128;
+
+static inline bool inv_geq(const uint64_t a[4], const uint64_t b[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > b[i]) return true;
+    if (a[i] < b[i]) return false;
   }
-  return r;
+  return true;
+}
+static inline uint64_t inv_add(uint64_t a[4], const uint64_t b[4]) {  // a += b, returns the carry
+  inv_u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (inv_u128)a[i] + b[i];
+    a[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  return (uint64_t)c;
+}
+static inline void inv_sub(uint64_t a[4], const uint64_t b[4]) {  // a -= b (mod 2^256)
+  uint64_t bw = 0;
+  for (int i = 0; i < 4; i++) {
+    inv_u128 t = (inv_u128)a[i] - b[i] - bw;
+    a[i] = (uint64_t)t;
+    bw = (uint64_t)(t >> 64) & 1;
+  }
+}
+static inline void inv_shr1(uint64_t a[4], uint64_t top) {  // a = (top:a) >> 1
+  a[0] = (a[0] >> 1) | (a[1] << 63);
+  a[1] = (a[1] >> 1) | (a[2] << 63);
+  a[2] = (a[2] >> 1) | (a[3] << 63);
+  a[3] = (a[3] >> 1) | (top << 63);
+}
+// x <- x / 2 mod m (m odd)
+static inline void inv_half(uint64_t x[4], const uint64_t m[4]) {
+  uint64_t top = 0;
+  if (x[0] & 1) top = inv_add(x, m);
+  inv_shr1(x, top);
+}
+static inline bool inv_is_one(const uint64_t a[4]) { return a[0] == 1 && (a[1] | a[2] | a[3]) == 0; }
+
+// out = a^-1 mod m for an odd prime m and a < m; 0 for a = 0.  Binary extended Euclid (HAC 14.61 for odd moduli):
+// invariants x1 * a = u, x2 * a = v (mod m).
+static inline void modinv256(const uint64_t a[4], const uint64_t m[4], uint64_t out[4]) {
+  uint64_t u[4] = {a[0], a[1], a[2], a[3]}, v[4] = {m[0], m[1], m[2], m[3]};
+  uint64_t x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+  if ((u[0] | u[1] | u[2] | u[3]) == 0) {
+    memset(out, 0, 32);
+    return;
+  }
+  while (!inv_is_one(u) && !inv_is_one(v)) {
+    while (!(u[0] & 1)) {
+      inv_shr1(u, 0);
+      inv_half(x1, m);
+    }
+    while (!(v[0] & 1)) {
+      inv_shr1(v, 0);
+      inv_half(x2, m);
+    }
+    if (inv_geq(u, v)) {
+      inv_sub(u, v);
+      if (!inv_geq(x1, x2)) inv_add(x1, m);  // the sum wraps 2^256 only together with the subtraction below
+      inv_sub(x1, x2);
+    } else {
+      inv_sub(v, u);
+      if (!inv_geq(x2, x1)) inv_add(x2, m);
+      inv_sub(x2, x1);
+    }
+  }
+  memcpy(out, inv_is_one(u) ? x1 : x2, 32);
+}
+
+// a^-1 (Montgomery form in and out); inverse of 0 is 0
+static inline Fr4 fr_inv(const Fr4& a) {
+  // the plain inverse of a R is a^-1 R^-1; two Montgomery products with R^2 bring it to a^-1 R
+  Fr4 x, r2 = {{FR_R2[0], FR_R2[1], FR_R2[2], FR_R2[3]}};
+  modinv256(a.v, FR_M, x.v);
+  return fr_mul(fr_mul(x, r2), r2);
 }
 
 }  // namespace host

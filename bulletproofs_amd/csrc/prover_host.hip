@@ -11,6 +11,7 @@
 #include "prover.h"
 #include "fixedbase.h"
 #include "glv.h"
+#include "host_inv.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -466,7 +467,7 @@ int mk_challenges_dev(bp_ctx* ctx, ProverWs& w, ShowStyle style, uint8_t acc[64]
         return rc;
       BP_TRY(hipMemcpyAsync(&ax, w.bit_out, sizeof(xyzz), hipMemcpyDeviceToHost, st));
       BP_TRY(hipStreamSynchronize(st));
-      affine an = xyzz_to_affine(ax);
+      affine an = host::xyzz_to_affine_host(ax);
       memcpy(acc, &an, 64);
     }
     return BP_OK;

@@ -22,6 +22,7 @@
 #include "devio.h"
 #include "fixedbase.h"
 #include "glv.h"
+#include "host_inv.h"
 #include "verify.h"
 
 namespace bp {
@@ -902,7 +903,7 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
       u256 y;
       memcpy(&y, challenges + ((size_t)0 * B + p) * 32, 32);
       y = Fr::to_mont(Fr::reduce_once(y));
-      u256 yi = Fr::inv(y), ym1i = Fr::inv(Fr::sub(y, Fr::one()));
+      u256 yi = host::fr_inv_mont_host(y), ym1i = host::fr_inv_mont_host(Fr::sub(y, Fr::one()));
       memcpy(vb->hinv + ((size_t)HI_YINV * B + p) * 32, &yi, 32);
       memcpy(vb->hinv + ((size_t)HI_YM1INV * B + p) * 32, &ym1i, 32);
     }
@@ -971,7 +972,7 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
     for (size_t p = 0; p < B; p++) {  // x_r^-1 on the host (`x` is host memory in both modes)
       u256 xv;
       memcpy(&xv, x + p * 32, 32);
-      xv = Fr::inv(Fr::to_mont(Fr::reduce_once(xv)));
+      xv = host::fr_inv_mont_host(Fr::to_mont(Fr::reduce_once(xv)));
       memcpy(vb->hinv + ((size_t)HI_XINV * B + p) * 32, &xv, 32);
     }
     hipLaunchKernelGGL(k_round_bits, dim3(d.B), dim3(256), 0, vb->stream, d, round, xin, vb->hinv, vb->xk_m, vb->xkinv_m,
@@ -1039,7 +1040,7 @@ int vbatch_join_side(bp_vbatch* vb) {
 int vbatch_collect(bp_vbatch* vb, uint8_t* out_commitment) {
   if (!vb->split || !vb->collect_pending) return BP_OK;
   for (size_t p = 0; p < vb->d.B; p++) {
-    affine a = xyzz_to_affine(vb->hx[p]);
+    affine a = host::xyzz_to_affine_host(vb->hx[p]);
     memcpy(out_commitment + p * 64, &a, 64);
   }
   vb->collect_pending = false;

@@ -157,6 +157,24 @@ extern "C" void hs_glv_bit_lanes(const uint8_t* k, const uint8_t* pt, uint8_t* o
   sta(out, xyzz_to_affine(acc));
 }
 
+// ---- host-side inversion of the latency paths (host_inv.h) ----
+#include "../../bulletproofs_amd/csrc/host_inv.h"
+// which: 0 = 1/a mod p (weak input allowed), 1 = x^-1 mod r through the Montgomery-form wrapper, 2 = host Fr4 fr_inv
+extern "C" void hs_host_inv(int which, const uint8_t* a, uint8_t* out) {
+  if (which == 0) {
+    st(out, bp::host::fq_inv_host(ld(a)));
+  } else if (which == 1) {
+    st(out, Fr::from_mont(bp::host::fr_inv_mont_host(Fr::to_mont(ld(a)))));
+  } else {
+    bp::host::fr_to_bytes(bp::host::fr_inv(bp::host::fr_from_bytes(a)), out);
+  }
+}
+extern "C" void hs_xyzz_to_affine_host(const uint8_t* xyzz128, uint8_t* out) {
+  xyzz p;
+  p.X = ld(xyzz128); p.Y = ld(xyzz128 + 32); p.ZZ = ld(xyzz128 + 64); p.ZZZ = ld(xyzz128 + 96);
+  sta(out, bp::host::xyzz_to_affine_host(p));
+}
+
 // ---- device decimal formatter (dec.h): 80-byte record of a 32-byte LE integer ----
 #include "../../bulletproofs_amd/csrc/dec.h"
 extern "C" void hs_dec_record(const uint8_t* le, uint8_t* rec80) {

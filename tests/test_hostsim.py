@@ -18,7 +18,10 @@ P, R = o.P, o.R
 def hs():
     so = os.path.join(HERE, "hostsim", "libhostsim.so")
     src = os.path.join(HERE, "hostsim", "hostsim.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    csrc = os.path.join(os.path.dirname(HERE), "bulletproofs_amd", "csrc")
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)
+                                            if f.endswith(".h")])
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     return ctypes.CDLL(so)
 
@@ -189,6 +192,34 @@ def test_glv_bit_lanes(hs):
         assert dp(out.raw) == o.point_mul(A, k)
     out = ctypes.create_string_buffer(64)
     hs.hs_glv_bit_lanes(b(rng.randrange(R)), pb(None), out)
+    assert dp(out.raw) is None
+
+
+def test_host_side_inversions(hs):
+    """host_inv.h / host_fr.h: the binary extended Euclid the verifiers' latency paths run on the CPU (x_r^-1 mod r,
+    1/ZZZ mod p), against Python's modular inverse; 0 maps to 0, weakly reduced base-field inputs are accepted."""
+    rng = random.Random(79)
+    for which, mod in ((0, P), (1, R), (2, R)):
+        vals = [1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, 2**128, 2**255 % mod] + [rng.randrange(1, mod) for _ in range(300)]
+        for a in vals:
+            out = ctypes.create_string_buffer(32)
+            hs.hs_host_inv(which, b(a), out)
+            assert int.from_bytes(out.raw, "little") == pow(a, -1, mod), (which, a)
+        out = ctypes.create_string_buffer(32)
+        hs.hs_host_inv(which, b(0), out)
+        assert out.raw == bytes(32)
+    out = ctypes.create_string_buffer(32)
+    hs.hs_host_inv(0, b(P + 5), out)      # weak representation of 5
+    assert int.from_bytes(out.raw, "little") == pow(5, -1, P)
+    # normalisation of an XYZZ point: (x z^2, y z^3, z^2, z^3) -> (x, y)
+    A = o.point_mul(o.GEN, rng.randrange(1, R))
+    for z in (1, 2, P - 1, rng.randrange(1, P)):
+        raw = b(A[0] * z * z % P) + b(A[1] * pow(z, 3, P) % P) + b(z * z % P) + b(pow(z, 3, P))
+        out = ctypes.create_string_buffer(64)
+        hs.hs_xyzz_to_affine_host(raw, out)
+        assert dp(out.raw) == A
+    out = ctypes.create_string_buffer(64)
+    hs.hs_xyzz_to_affine_host(bytes(128), out)
     assert dp(out.raw) is None
 
 
