@@ -205,7 +205,6 @@ int ac_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t n2, uint32_t k, 
   // commitBitVector (Internal.hs:102-107): aiCommit, aoCommit (vR = []), sCommit   (Prover.hs:29-33)
   uint32_t* d_tb = (uint32_t*)w.pts;
   xyzz* d_part = (xyzz*)(w.pts + tb_bytes);
-  uint8_t* d_out = w.small + 64;
   std::vector<uint32_t> tb(nterms);
   for (uint32_t i = 0; i < n2; i++) {
     tb[i] = fb_base_g(i);
@@ -216,9 +215,8 @@ int ac_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t n2, uint32_t k, 
   if ((rc = frv_ac_commit_scalars(ctx, n2, aL, aR, aO, sL, sR, bytes_as_u256(blind3), bytes_as_u256(blind3 + 32),
                                   bytes_as_u256(blind3 + 64), w.sc)) != BP_OK)
     return rc;
-  if ((rc = fb_msm_launch(ctx, 3, nterms, w.sc, d_tb, d_part, nullptr, d_out)) != BP_OK) return rc;
-  BP_TRY(hipMemcpyAsync(AI, d_out, 192, hipMemcpyDeviceToHost, st));
-  BP_TRY(hipStreamSynchronize(st));
+  if ((rc = fb_msm_launch(ctx, 3, nterms, w.sc, d_tb, d_part, nullptr, w.xout)) != BP_OK) return rc;
+  if ((rc = fb_msm_fetch(ctx, w, 3, AI)) != BP_OK) return rc;
   const Fr4 aiB = fr_from_bytes(blind3), aoB = fr_from_bytes(blind3 + 32), sB = fr_from_bytes(blind3 + 64);
 
   uint8_t yb[32], zb[32], xb[32];

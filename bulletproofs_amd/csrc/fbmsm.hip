@@ -5,8 +5,9 @@
 // generators with expanded scalars instead of folding the generator vectors (prover_host.hip).
 //
 // One lane per term walks all windows of its scalar (one gathered table entry and one mixed addition per
-// non-zero digit, no doublings), workgroups sum their lanes, a second launch sums the workgroups, adds an
-// optional offset point to the first result and normalises.
+// non-zero digit, no doublings), workgroups sum their lanes, a second launch sums the workgroups and adds an
+// optional offset point to the first result.  The sums leave as XYZZ: the host, which waits for them anyway,
+// normalises them with one shared inversion in microseconds (host_inv.h), against ~0.14 ms for a GPU lane.
 #include <stdlib.h>
 #include "engine.h"
 #include "devio.h"
@@ -52,10 +53,10 @@ __global__ void __launch_bounds__(256) k_fb_msm_terms(uint32_t nterms, uint32_t 
   if (threadIdx.x == 0) st_xyzz(&partial[(size_t)msm * gridDim.x + blockIdx.x], s);
 }
 
-// out[msm] = affine(sum of the msm's partials (+ offset for msm 0)); one wave when there are at most 64 partials
+// out[msm] = sum of the msm's partials (+ offset for msm 0), XYZZ; one wave when there are at most 64 partials
 __global__ void __launch_bounds__(256) k_fb_msm_finish(uint32_t nblk, const xyzz* __restrict__ partial,
                                                       const uint8_t* __restrict__ offset /*64 B affine, or null*/,
-                                                      uint8_t* __restrict__ out /*[nmsm][64]*/) {
+                                                      xyzz* __restrict__ out /*[nmsm]*/) {
   __shared__ xyzz red[4];
   const uint32_t msm = blockIdx.x;
   xyzz acc = xyzz_inf(), s;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(256) k_fb_msm_finish(uint32_t nblk, const xyzz
   }
   if (threadIdx.x == 0) {
     if (msm == 0 && offset) s = xyzz_madd(s, ld_affine(offset));
-    st_affine(out + (size_t)msm * 64, xyzz_to_affine(s));
+    st_xyzz(&out[msm], s);
   }
 }
 
@@ -95,9 +96,9 @@ size_t fb_msm_partials(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms) {
 }
 
 // nmsm sums over the same nterms bases; d_scalars [nmsm][nterms][32] canonical, d_term_base [nterms] table base
-// indices (fixedbase.h), d_partial: fb_msm_partials() XYZZ of scratch, d_out: nmsm affine points.
+// indices (fixedbase.h), d_partial: fb_msm_partials() XYZZ of scratch, d_out: nmsm sums, XYZZ (not normalised).
 int fb_msm_launch(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms, const uint8_t* d_scalars, const uint32_t* d_term_base,
-                  xyzz* d_partial, const uint8_t* d_offset, uint8_t* d_out) {
+                  xyzz* d_partial, const uint8_t* d_offset, xyzz* d_out) {
   if (!ctx->d_table || ctx->n_gens == 0) {
     ctx->err = "generators not set (bp_ctx_set_generators)";
     return BP_ERR_STATE;

@@ -38,5 +38,28 @@ static inline affine xyzz_to_affine_host(const xyzz& p) {
   return xyzz_to_affine_with_inv(p, fq_inv_host(p.ZZZ));
 }
 
+// n points with ONE inversion (Montgomery's trick over the finite ones)
+static inline void xyzz_batch_to_affine_host(const xyzz* p, int n, affine* out) {
+  enum { CHUNK = 32 };
+  for (int base = 0; base < n; base += CHUNK) {
+    const int cnt = n - base < CHUNK ? n - base : CHUNK;
+    u256 pre[CHUNK], acc = u256_one();
+    for (int i = 0; i < cnt; i++) {
+      pre[i] = acc;
+      if (!xyzz_is_inf(p[base + i])) acc = fq_mul(acc, p[base + i].ZZZ);
+    }
+    u256 inv = fq_inv_host(acc);
+    for (int i = cnt - 1; i >= 0; i--) {
+      const xyzz& q = p[base + i];
+      if (xyzz_is_inf(q)) {
+        out[base + i] = affine_inf();
+        continue;
+      }
+      out[base + i] = xyzz_to_affine_with_inv(q, fq_mul(inv, pre[i]));
+      inv = fq_mul(inv, q.ZZZ);
+    }
+  }
+}
+
 }  // namespace host
 }  // namespace bp

@@ -34,6 +34,7 @@ struct ProverWs {
   uint8_t* bit_pts;
   xyzz* bit_sh;
   xyzz* bit_out;  // 8 entries; entry 0 is the running commitment of mk_challenges_dev
+  xyzz* xout;     // 16 entries: the sums of fb_msm_launch, XYZZ (fb_msm_fetch normalises them on the host)
   FrDev fr;            // scalar-field vectors (frvec.hip)
 };
 
@@ -106,7 +107,12 @@ bool prover_uses_fixed_base();
 // XYZZ partial sums fb_msm_launch needs at d_partial for these dimensions
 size_t fb_msm_partials(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms);
 int fb_msm_launch(bp_ctx* ctx, uint32_t nmsm, uint32_t nterms, const uint8_t* d_scalars, const uint32_t* d_term_base,
-                  xyzz* d_partial, const uint8_t* d_offset, uint8_t* d_out);
+                  xyzz* d_partial, const uint8_t* d_offset, xyzz* d_out);
+// The sums of the last fb_msm_launch(..., w.xout) as affine points in host memory: one device-to-host copy of the
+// nmsm XYZZ results and of `tail_bytes` more device bytes right behind them (into tail_host), a stream
+// synchronisation, and the normalisation on the host (one shared inversion, host_inv.h).
+int fb_msm_fetch(bp_ctx* ctx, ProverWs& w, uint32_t nmsm, uint8_t* out /*[nmsm][64]*/, void* tail_host = nullptr,
+                 size_t tail_bytes = 0);
 
 // ---- frvec.hip: launch wrappers, asynchronous on ctx->stream; all pointers are device memory ----------------------
 struct IppVArgs {

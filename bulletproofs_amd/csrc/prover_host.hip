@@ -34,6 +34,7 @@ int carve_ws(bp_ctx* ctx, uint32_t n, ProverWs& w, uint32_t extra) {
     w.bit_pts = c.take<uint8_t>((size_t)w.bit_cap * 64);
     w.bit_sh = c.take<xyzz>((size_t)w.bit_cap * GLV_LANE_BITS);
     w.bit_out = c.take<xyzz>(8);
+    w.xout = c.take<xyzz>(16);
     w.fr.cap = n;
     w.fr.ls = c.take<u256>(n);
     w.fr.rs = c.take<u256>(n);
@@ -276,15 +277,27 @@ int fb_msm_host(bp_ctx* ctx, ProverWs& w, const std::vector<uint32_t>& term_base
   }
   uint32_t* d_tb = (uint32_t*)w.pts;
   xyzz* d_part = (xyzz*)(w.pts + tb_bytes);
-  uint8_t* d_out = w.small + 64;
   BP_TRY(hipMemcpyAsync(d_tb, term_base.data(), (size_t)nterms * 4, hipMemcpyHostToDevice, st));
   BP_TRY(hipMemcpyAsync(w.sc, hsc.data(), hsc.size(), hipMemcpyHostToDevice, st));
-  int rc = fb_msm_launch(ctx, nmsm, nterms, w.sc, d_tb, d_part, nullptr, d_out);
+  int rc = fb_msm_launch(ctx, nmsm, nterms, w.sc, d_tb, d_part, nullptr, w.xout);
   if (rc != BP_OK) return rc;
   uint8_t out[15 * 64];
-  BP_TRY(hipMemcpyAsync(out, d_out, (size_t)nmsm * 64, hipMemcpyDeviceToHost, st));
-  BP_TRY(hipStreamSynchronize(st));
+  if ((rc = fb_msm_fetch(ctx, w, nmsm, out)) != BP_OK) return rc;
   for (uint32_t j = 0; j < nmsm; j++) memcpy(outs[j], out + (size_t)j * 64, 64);
+  return BP_OK;
+}
+
+int fb_msm_fetch(bp_ctx* ctx, ProverWs& w, uint32_t nmsm, uint8_t* out, void* tail_host, size_t tail_bytes) {
+  BP_REQUIRE(nmsm >= 1 && (size_t)nmsm * sizeof(xyzz) + tail_bytes <= 16 * sizeof(xyzz), "fb_msm_fetch: too many results");
+  alignas(16) uint8_t stage[16 * sizeof(xyzz)];
+  BP_TRY(hipMemcpyAsync(stage, w.xout, (size_t)nmsm * sizeof(xyzz) + tail_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  BP_TRY(hipStreamSynchronize(ctx->stream));
+  affine a[16];
+  xyzz px[16];
+  memcpy((void*)px, stage, (size_t)nmsm * sizeof(xyzz));
+  xyzz_batch_to_affine_host(px, (int)nmsm, a);
+  memcpy(out, (const void*)a, (size_t)nmsm * 64);
+  if (tail_bytes) memcpy(tail_host, stage + (size_t)nmsm * sizeof(xyzz), tail_bytes);
   return BP_OK;
 }
 
@@ -323,7 +336,6 @@ int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<Fr4>
   uint32_t* d_tb = (uint32_t*)w.pts;
   xyzz* d_part = (xyzz*)(w.pts + (((size_t)nterms * 4 + 255) & ~(size_t)255));
   uint8_t* d_off = w.small;
-  uint8_t* d_out = w.small + 64;
   {
     std::vector<uint32_t> tb(nterms);
     for (uint32_t i = 0; i < n; i++) {
@@ -387,11 +399,9 @@ int ipp_prove_fixed(bp_ctx* ctx, ProverWs& w, uint32_t n, const std::vector<Fr4>
     fr_to_bytes(fr_mul(ubm, cL), L + (size_t)2 * n * 32);
     fr_to_bytes(fr_mul(ubm, cR), R + (size_t)2 * n * 32);
     BP_TRY(hipMemcpyAsync(d_sc, hsc.data(), hsc.size(), hipMemcpyHostToDevice, st));
-    int rc = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, d_out);
+    int rc = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, w.xout);
     if (rc != BP_OK) return rc;
-    BP_TRY(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st));
-    BP_TRY(hipStreamSynchronize(st));
-    return BP_OK;
+    return fb_msm_fetch(ctx, w, 3, (uint8_t*)out);
   };
   int rc;
   uint32_t nk = n;
@@ -531,7 +541,6 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
   uint32_t* d_tb = (uint32_t*)w.pts;
   xyzz* d_part = (xyzz*)(w.pts + (((size_t)nterms * 4 + 255) & ~(size_t)255));
   uint8_t* d_off = w.small;
-  uint8_t* d_out = w.small + 64;
   int rc;
   const u256 ubm = fr4_as_u256(fr_from_bytes(ub));
   const u256 zero = u256_zero();
@@ -539,12 +548,10 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
     uint8_t pts[3][64];
     uint8_t sm[3][32];
   } res;
-  u256* d_sm = (u256*)(d_out + sizeof(res.pts));  // dot, l, r right behind the three points: one copy per round
+  u256* d_sm = (u256*)(w.xout + 3);  // dot, l, r right behind the three sums: one copy per round
   auto fetch = [&](bool points) -> int {
-    if (points)
-      BP_TRY(hipMemcpyAsync(&res, d_out, sizeof(res), hipMemcpyDeviceToHost, st));
-    else
-      BP_TRY(hipMemcpyAsync(res.sm, d_sm, sizeof(res.sm), hipMemcpyDeviceToHost, st));
+    if (points) return fb_msm_fetch(ctx, w, 3, &res.pts[0][0], res.sm, sizeof(res.sm));
+    BP_TRY(hipMemcpyAsync(res.sm, d_sm, sizeof(res.sm), hipMemcpyDeviceToHost, st));
     BP_TRY(hipStreamSynchronize(st));
     return BP_OK;
   };
@@ -572,7 +579,7 @@ int ipp_prove_fixed_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, const u256* d_hsca
   auto launch = [&](uint32_t nk_prev, bool fold, const u256& x, const u256& xi) -> int {
     int r2 = frv_ipp_round(ctx, n, nk_prev, fold, x, xi, ubm, f.ls, f.rs, f.cg, f.ch, d_sc, d_sm, true);
     if (r2 != BP_OK) return r2;
-    if ((r2 = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, d_out)) != BP_OK) return r2;
+    if ((r2 = fb_msm_launch(ctx, 3, nterms, d_sc, d_tb, d_part, d_off, w.xout)) != BP_OK) return r2;
     return fetch(true);
   };
   uint32_t nk = n;
@@ -636,7 +643,6 @@ static int rangeproof_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t m
   }
   uint32_t* d_tb = (uint32_t*)w.pts;
   xyzz* d_part = (xyzz*)(w.pts + tb_bytes);
-  uint8_t* d_out = w.small + 64;
   // commitBitVectors: A = aBlinding*h + <aL, gs> + <aR, hs>, S likewise   (RangeProof/Internal.hs:136-147)
   std::vector<uint32_t> tb(nterms);
   for (uint32_t i = 0; i < nm; i++) {
@@ -650,9 +656,8 @@ static int rangeproof_prove_dev(bp_ctx* ctx, ProverWs& w, uint32_t n, uint32_t m
   BP_TRY(hipMemcpyAsync(raw_sR, sR, (size_t)nm * 32, hipMemcpyHostToDevice, st));
   if ((rc = frv_rp_commit_scalars(ctx, nm, f.bits, raw_sL, raw_sR, bytes_as_u256(alpha), bytes_as_u256(rho), w.sc)) != BP_OK)
     return rc;
-  if ((rc = fb_msm_launch(ctx, 2, nterms, w.sc, d_tb, d_part, nullptr, d_out)) != BP_OK) return rc;
-  BP_TRY(hipMemcpyAsync(A, d_out, 128, hipMemcpyDeviceToHost, st));
-  BP_TRY(hipStreamSynchronize(st));  // A, S are in; tb, bits live on this frame
+  if ((rc = fb_msm_launch(ctx, 2, nterms, w.sc, d_tb, d_part, nullptr, w.xout)) != BP_OK) return rc;
+  if ((rc = fb_msm_fetch(ctx, w, 2, A)) != BP_OK) return rc;  // A, S are in; tb, bits live on this frame
   // queued now, they run while the host hashes y and z
   if ((rc = frv_from_bytes(ctx, raw_sL, nm, l1)) != BP_OK) return rc;  // l1 = sL (Prover.hs:143)
   if ((rc = frv_from_bytes(ctx, raw_sR, nm, sRm)) != BP_OK) return rc;

@@ -44,6 +44,10 @@ class Pool {
   int size() const { return n_; }
   void run(const std::function<void(size_t, size_t)>& f, size_t n, size_t grain = 64) {
     if (n == 0) return;
+    if (n <= grain || n_ == 1) {  // one block: waking the workers (~30 us) would cost more than the work
+      f(0, n);
+      return;
+    }
     fn_ = &f;
     total_ = n;
     grain_ = grain;
@@ -401,13 +405,16 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
       if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc, ch.acc_txt, ch.lr_txt)) != BP_OK) return rc;
     } else if (stage[pick] <= k) {
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;  // completed already: folds the profiling events in
+      TRACE("wait", pick, stage[pick] - 1, t_h);
       if ((rc = vbatch_collect(ch.vb, ch.acc)) != BP_OK) return rc;
+      TRACE("collect", pick, stage[pick] - 1, t_h);
       uint32_t r = stage[pick] - 1;
       // round 0 hashes the text of L_0, R_0 that k_dec_numbers wrote on the SIDE stream: join it first
       if (r == 0 && (rc = vbatch_join_side(ch.vb)) != BP_OK) return rc;
       hashR(ch, r);
       TRACE("hashR", pick, r, t_h);
       if ((rc = vbatch_round_async(ch.vb, r, ch.xk, ch.acc, ch.acc_txt)) != BP_OK) return rc;
+      TRACE("launch", pick, r, t_h);
     } else {
       if ((rc = vbatch_wait(ch.vb)) != BP_OK) return rc;
       if ((rc = vbatch_finish_async(ch.vb, ch.verdict)) != BP_OK) return rc;
