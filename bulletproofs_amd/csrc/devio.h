@@ -77,6 +77,25 @@ __device__ __forceinline__ xyzz wave_sum_width(xyzz v, int width) {
   }
   return v;
 }
+// Inclusive suffix scan over a workgroup of up to 256 threads: thread t gets the sum over threads t' >= t.
+// Shuffle steps inside a wave (6 additions deep), then each wave adds the totals of the waves behind it.
+// `lds` must hold blockDim.x/64 xyzz values.
+__device__ __forceinline__ xyzz block_suffix_scan(xyzz v, xyzz* lds) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll 1
+  for (int d = 1; d < 64; d <<= 1) {
+    xyzz o = shfl_down_xyzz(v, d);
+    if (lane + d < 64) v = xyzz_add(v, o);
+  }
+  if (nw == 1) return v;
+  if (lane == 0) lds[wid] = v;
+  __syncthreads();
+  xyzz later = xyzz_inf();
+  for (int w2 = nw - 1; w2 > wid; w2--) later = xyzz_add(later, lds[w2]);
+  __syncthreads();
+  return xyzz_add(v, later);
+}
+
 // This lane's term of k * point (k canonical, < r) from the point's bit table tab[j] = 2^j * point (glv.h glv_bit_lane)
 __device__ __forceinline__ xyzz bit_lane_term(const u256& k, const xyzz* __restrict__ tab, int j) {
   GlvHalf h1, h2;

@@ -105,8 +105,23 @@ __global__ void __launch_bounds__(256) k_rank_top(uint32_t ne, MsmPlan pl, const
   uint32_t code = j < ne ? codes[(size_t)w * ne + j] : MSM_SKIP;
   bool valid = code != MSM_SKIP;
   uint32_t bucket = (code & ~MSM_NEG) & 31u;
+  // one LDS atomic per wave and distinct bucket (there are one or two): the lanes of a bucket rank themselves by ballot
   uint32_t local = 0;
-  if (valid) local = atomicAdd(&cnt[bucket], 1u);
+  {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t b = (uint32_t)__shfl((int)bucket, leader, 64);
+      const bool mine = valid && bucket == b;
+      const uint64_t m = __ballot(mine);
+      uint32_t basew = 0;
+      if (lane == (uint32_t)leader) basew = atomicAdd(&cnt[b], (uint32_t)__popcll(m));
+      basew = (uint32_t)__shfl((int)basew, leader, 64);
+      if (mine) local = basew + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      todo &= ~m;
+    }
+  }
   __syncthreads();
   if (threadIdx.x < 32 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[(size_t)w * pl.nb + threadIdx.x], cnt[threadIdx.x]);
   __syncthreads();
@@ -278,10 +293,22 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
   int w = w0 + blockIdx.x, t = threadIdx.x;
   int per = (pl.nb + 1023) / 1024;
   const uint32_t* h = hist + (size_t)w * pl.nb;
+  const bool vec = (per & 3) == 0 && (pl.nb & 3) == 0;  // a thread's run as uint4 pieces: independent loads in flight together
   uint32_t sum = 0;
-  for (int k = 0; k < per; k++) {
-    int b = t * per + k;
-    if (b < pl.nb) sum += h[b];
+  if (vec) {
+    const uint4* h4 = (const uint4*)h;
+    for (int k = 0; k < per / 4; k++) {
+      int b4 = t * (per / 4) + k;
+      if (b4 * 4 < pl.nb) {
+        uint4 v = h4[b4];
+        sum += v.x + v.y + v.z + v.w;
+      }
+    }
+  } else {
+    for (int k = 0; k < per; k++) {
+      int b = t * per + k;
+      if (b < pl.nb) sum += h[b];
+    }
   }
   part[t] = sum;
   __syncthreads();
@@ -292,12 +319,31 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
     __syncthreads();
   }
   uint32_t run = (uint32_t)((size_t)w * n) + part[t] - sum;  // exclusive
-  for (int k = 0; k < per; k++) {
-    int b = t * per + k;
-    if (b < pl.nb) {
-      offs[(size_t)w * pl.nb + b] = run;
-      cursor[(size_t)w * pl.nb + b] = run;
-      run += h[b];
+  if (vec) {
+    const uint4* h4 = (const uint4*)h;
+    uint4* o4 = (uint4*)(offs + (size_t)w * pl.nb);
+    uint4* c4 = (uint4*)(cursor + (size_t)w * pl.nb);
+    for (int k = 0; k < per / 4; k++) {
+      int b4 = t * (per / 4) + k;
+      if (b4 * 4 < pl.nb) {
+        uint4 v = h4[b4], o;
+        o.x = run;
+        o.y = o.x + v.x;
+        o.z = o.y + v.y;
+        o.w = o.z + v.z;
+        run = o.w + v.w;
+        o4[b4] = o;
+        c4[b4] = o;
+      }
+    }
+  } else {
+    for (int k = 0; k < per; k++) {
+      int b = t * per + k;
+      if (b < pl.nb) {
+        offs[(size_t)w * pl.nb + b] = run;
+        cursor[(size_t)w * pl.nb + b] = run;
+        run += h[b];
+      }
     }
   }
 }
@@ -555,6 +601,52 @@ __global__ void __launch_bounds__(256) k_window_sum(const xyzz* __restrict__ seg
   if (threadIdx.x == 0) st_xyzz(&wsum[w], acc);
 }
 
+// ---- 6'/7'. the same weighted sums by suffix scans (nb <= 65,536) -------------------------------------------------
+// sum_b (b + 1) B[b] = sum_b suffix(b), suffix(b) = sum_{b' >= b} B[b'].  A workgroup scans 256 buckets (8 additions
+// deep) and sums its suffixes (8 more): tb = sum_t (t + 1) B[256 blk + t] and the workgroup total bt.  Then
+//   R_w = sum_blk tb[blk] + 256 * sum_blk blk * bt[blk],
+// the second sum being the suffixes of bt from blk = 1 on: one more scan over at most 256 totals.  About 40 additions
+// deep in all, against ~75 for the segment running sums above (whose lanes also multiply by the segment index).
+__global__ void __launch_bounds__(256) k_bucket_scan(const xyzz* __restrict__ buckets, uint32_t nb, uint32_t nblk,
+                                                    xyzz* __restrict__ bt /*[W][nblk]*/, xyzz* __restrict__ tb /*[W][nblk]*/) {
+  __shared__ xyzz wt[4], red[4];
+  const uint32_t w = blockIdx.y, blk = blockIdx.x, b = blk * 256u + threadIdx.x;
+  xyzz v = xyzz_inf();
+  if (b < nb) v = ld_xyzz(&buckets[(size_t)w * nb + b]);
+  v = block_suffix_scan(v, wt);
+  if (threadIdx.x == 0) st_xyzz(&bt[(size_t)w * nblk + blk], v);
+  xyzz s = block_sum(v, red);
+  if (threadIdx.x == 0) st_xyzz(&tb[(size_t)w * nblk + blk], s);
+}
+// wsum2[w][0] = 256 * sum_blk blk * bt[w][blk], wsum2[w][1] = sum_blk tb[w][blk]; blockIdx.y selects the half
+__global__ void __launch_bounds__(256) k_bucket_sum(const xyzz* __restrict__ bt, const xyzz* __restrict__ tb, uint32_t nblk,
+                                                   xyzz* __restrict__ wsum2 /*[W][2]*/) {
+  __shared__ xyzz wt[4], red[4];
+  const uint32_t w = blockIdx.x, t = threadIdx.x;
+  xyzz v = xyzz_inf();
+  if (blockIdx.y == 1) {
+    if (t < nblk) v = ld_xyzz(&tb[(size_t)w * nblk + t]);
+    xyzz s = block_sum(v, red);
+    if (t == 0) st_xyzz(&wsum2[2 * w + 1], s);
+    return;
+  }
+  if (t < nblk) v = ld_xyzz(&bt[(size_t)w * nblk + t]);
+  v = block_suffix_scan(v, wt);
+  xyzz s = block_sum(t >= 1 ? v : xyzz_inf(), red);
+  if (t == 0) {
+    if (nblk > 1)
+      for (int i = 0; i < 8; i++) s = xyzz_dbl(s);
+    st_xyzz(&wsum2[2 * w], s);
+  }
+}
+__global__ void __launch_bounds__(64) k_final2(const xyzz* __restrict__ wsum2, MsmPlan pl, uint8_t* __restrict__ out_affine,
+                                              xyzz* __restrict__ out_xyzz) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xyzz r = window_combine(pl, [&](int w) { return xyzz_add(ld_xyzz(&wsum2[2 * w]), ld_xyzz(&wsum2[2 * w + 1])); });
+  if (out_xyzz) st_xyzz(out_xyzz, r);
+  if (out_affine) st_affine(out_affine, xyzz_to_affine(r));
+}
+
 // ---- 8. Horner over windows + normalise ------------------------------------------------------
 __global__ void __launch_bounds__(64) k_final(const xyzz* __restrict__ wsum, MsmPlan pl, uint8_t* __restrict__ out_affine,
                         xyzz* __restrict__ out_xyzz) {
@@ -770,8 +862,12 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     heavy_off = cv.take<uint32_t>(max_heavy + 1);
     partial = cv.take<xyzz>(max_slices);
     buckets = cv.take<xyzz>(nbt);
-    segv = cv.take<xyzz>((size_t)pl.W * pl.nseg);
-    wsum = cv.take<xyzz>(pl.W);
+    {
+      const size_t scan_vals = (size_t)2 * pl.W * (((size_t)pl.nb + 255) / 256);  // k_bucket_scan's bt, tb
+      const size_t seg_vals = (size_t)pl.W * pl.nseg;
+      segv = cv.take<xyzz>(seg_vals > scan_vals ? seg_vals : scan_vals);
+    }
+    wsum = cv.take<xyzz>((size_t)2 * pl.W);
     (void)zero_end;
     return cv.off;
   };
@@ -868,6 +964,19 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   if (prep) {  // all windows weigh 1: add their buckets index by index, then reduce ONE window; no Horner chain
     hipLaunchKernelGGL(k_combine_windows, dim3((pl.nb + 255) / 256), dim3(256), 0, st, buckets, (uint32_t)pl.W, (uint32_t)pl.nb);
     pl.W = 1;
+  }
+  static const bool tail_segments = getenv("BP_MSM_TAIL") && !strcmp(getenv("BP_MSM_TAIL"), "segments");
+  // the scan does ~17 additions per bucket against ~2 for the running sums: it pays while the launch stays within
+  // about a wave per SIMD (latency-bound), i.e. for one combined window or small plans
+  if (pl.nb <= 65536 && (size_t)pl.W * pl.nb <= 65536 && !tail_segments) {
+    const uint32_t nblk = ((uint32_t)pl.nb + 255u) / 256u;  // <= 256
+    xyzz* bt = segv;  // [W][nblk] twice (the carve sizes segv for both tails)
+    xyzz* tb = segv + (size_t)pl.W * nblk;
+    hipLaunchKernelGGL(k_bucket_scan, dim3(nblk, pl.W), dim3(256), 0, st, buckets, (uint32_t)pl.nb, nblk, bt, tb);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(pl.W, 2), dim3(256), 0, st, bt, tb, nblk, wsum);
+    hipLaunchKernelGGL(k_final2, dim3(1), dim3(64), 0, st, wsum, pl, (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
+    BP_TRY(hipGetLastError());
+    return BP_OK;
   }
   uint32_t nsegt = (uint32_t)pl.W * pl.nseg;
   hipLaunchKernelGGL(k_seg_reduce, dim3((nsegt + 255) / 256), dim3(256), 0, st, buckets, pl, segv);
