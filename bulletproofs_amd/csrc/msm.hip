@@ -95,20 +95,24 @@ __global__ void __launch_bounds__(256) k_recode_glv(const uint8_t* __restrict__ 
 // The top window of the GLV form holds only the last few bits (2 for c = 16): a million entries would
 // hammer a handful of counters.  Ranks come from LDS counters per workgroup plus one global atomic per
 // workgroup and distinct bucket (at most 32 buckets: top_bits <= 5).
+constexpr int RT_PER = 8;  // entries per thread of k_rank_top
 __global__ void __launch_bounds__(256) k_rank_top(uint32_t ne, MsmPlan pl, const uint32_t* __restrict__ codes,
                                                  uint32_t* __restrict__ ranks, uint32_t* __restrict__ hist) {
   __shared__ uint32_t cnt[32], base[32];
   if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const int w = pl.W - 1;
-  uint32_t code = j < ne ? codes[(size_t)w * ne + j] : MSM_SKIP;
-  bool valid = code != MSM_SKIP;
-  uint32_t bucket = (code & ~MSM_NEG) & 31u;
-  // one LDS atomic per wave and distinct bucket (there are one or two): the lanes of a bucket rank themselves by ballot
-  uint32_t local = 0;
-  {
-    const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t local[RT_PER], bkt[RT_PER];
+#pragma unroll
+  for (int i = 0; i < RT_PER; i++) {
+    const uint32_t j = (blockIdx.x * RT_PER + i) * 256u + threadIdx.x;
+    const uint32_t code = j < ne ? codes[(size_t)w * ne + j] : MSM_SKIP;
+    const bool valid = code != MSM_SKIP;
+    const uint32_t bucket = (code & ~MSM_NEG) & 31u;
+    bkt[i] = valid ? bucket : 0xFFFFFFFFu;
+    local[i] = 0;
+    // one LDS atomic per wave and distinct bucket (there are one or two): the lanes of a bucket rank themselves by ballot
     uint64_t todo = __ballot(valid);
     while (todo) {
       const int leader = __builtin_ctzll(todo);
@@ -118,14 +122,18 @@ __global__ void __launch_bounds__(256) k_rank_top(uint32_t ne, MsmPlan pl, const
       uint32_t basew = 0;
       if (lane == (uint32_t)leader) basew = atomicAdd(&cnt[b], (uint32_t)__popcll(m));
       basew = (uint32_t)__shfl((int)basew, leader, 64);
-      if (mine) local = basew + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (mine) local[i] = basew + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       todo &= ~m;
     }
   }
   __syncthreads();
   if (threadIdx.x < 32 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[(size_t)w * pl.nb + threadIdx.x], cnt[threadIdx.x]);
   __syncthreads();
-  if (valid) ranks[(size_t)w * ne + j] = base[bucket] + local;
+#pragma unroll
+  for (int i = 0; i < RT_PER; i++) {
+    const uint32_t j = (blockIdx.x * RT_PER + i) * 256u + threadIdx.x;
+    if (bkt[i] != 0xFFFFFFFFu) ranks[(size_t)w * ne + j] = base[bkt[i]] + local[i];
+  }
 }
 
 // point of a sorted entry: plain index, or (index >> 1, endomorphism flag) in GLV form
@@ -910,7 +918,7 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     hipLaunchKernelGGL(k_recode_glv, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, 0u, n32, pl,
                        codes, ranks, hist);
   if (glv && GLV_BITS + 1 - pl.c * (pl.W - 1) <= 5)
-    hipLaunchKernelGGL(k_rank_top, dim3((ne32 + 255) / 256), dim3(256), 0, st, ne32, pl, codes, ranks, hist);
+    hipLaunchKernelGGL(k_rank_top, dim3((ne32 + 256 * RT_PER - 1) / (256 * RT_PER)), dim3(256), 0, st, ne32, pl, codes, ranks, hist);
   if (glv) {
   } else
     hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl, codes,
@@ -1126,7 +1134,10 @@ int msm_points_run(MsmPoints* mp, const void* d_scalars, const uint8_t* h_scalar
     int v = e ? atoi(e) : 0;
     return v >= 1 && v <= 8 ? v : 0;
   }();
-  pr.nchunks = env_chunks ? env_chunks : (mp->n >= (1u << 17) ? 8 : 1);
+  // One piece by default: since the two-level sort the recoding kernel takes ~0.08 ms at 2^20, so there is little left to
+  // hide the copy behind, and the per-piece events cost more than they save (measured inside bench.py: 4.66 ms with 8
+  // pieces against 2.94 ms with one).  BP_MSM_UPLOAD_CHUNKS=2..8 still selects the pipelined form.
+  pr.nchunks = env_chunks ? env_chunks : 1;
   if (h_scalars) {  // the previous call's recode kernels may still read the staging buffer
     BP_TRY(hipEventRecord(mp->ev_start, ctx->stream));
     BP_TRY(hipStreamWaitEvent(mp->copy_stream, mp->ev_start, 0));
