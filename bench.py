@@ -251,10 +251,21 @@ def msm_bench(eng, rank, world, dist, logns, iters):
                 for _ in range(iters):
                     mp.run(h_s.data_ptr())
                 dp = (time.perf_counter() - t0) / iters
-                mp.close()
                 row[kind]["prepared_ms"] = dp * 1e3
                 row[kind]["prepared_points_per_s"] = n / dp
                 row[kind]["prepared_frac"] = mads / dp / 1e12 / PEAK_TMAD
+                if kind == "uniform":  # scalars resident as well: the kernels alone
+                    mp.run_dev(d_s.data_ptr(), d_out.data_ptr())
+                    eng.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(iters):
+                        mp.run_dev(d_s.data_ptr(), d_out.data_ptr())
+                        eng.sync()
+                    dq = (time.perf_counter() - t0) / iters
+                    row[kind]["prepared_resident_ms"] = dq * 1e3
+                    row[kind]["prepared_resident_points_per_s"] = n / dq
+                    row[kind]["prepared_resident_frac"] = mads / dq / 1e12 / PEAK_TMAD
+                mp.close()
         out.append(row)
     return out
 
@@ -496,12 +507,17 @@ def main():
                 "metric": "MSM points/sec (secp256k1, BASELINE.json configs[2])",
                 "n": top["n"], "points_per_s": top["uniform"]["points_per_s"], "ms": top["uniform"]["ms"],
                 "frac": top["uniform"]["frac"],
+                "resident_points_per_s": top["uniform"].get("resident_points_per_s"),
                 "prepared_points_per_s": top["uniform"].get("prepared_points_per_s"),
                 "prepared_frac": top["uniform"].get("prepared_frac"),
-                "what": "sum e_i P_i, points resident (one-time upload excluded), scalars uploaded from pinned host "
-                        "memory every iteration (included), %d GPU(s) by contiguous point ranges + all-gather of "
-                        "64-byte partial sums; frac = SURVEY 8d algorithmic mads / (time x %d x %.1f Tmad/s)"
-                        % (world, world, PEAK_TMAD),
+                "prepared_resident_points_per_s": top["uniform"].get("prepared_resident_points_per_s"),
+                "prepared_resident_frac": top["uniform"].get("prepared_resident_frac"),
+                "what": "sum e_i P_i over uniform 256-bit scalars, points resident in HBM (one-time upload excluded), "
+                        "%d GPU(s) by contiguous point ranges + all-gather of 64-byte partial sums.  points_per_s / "
+                        "prepared_points_per_s: scalars uploaded from pinned host memory every iteration (included); "
+                        "resident_* : scalars resident as well.  prepared_*: bp_msm_points handle over the same points "
+                        "(one-time shifted copies 2^(16 w) P, no window doublings at run time; N = 1 only).  "
+                        "frac = SURVEY 8d algorithmic mads / (time x %d x %.1f Tmad/s)" % (world, world, PEAK_TMAD),
                 "sweep": msm,
             }
         if strong:
