@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "../bulletproofs_amd/csrc/ec.h"
+#include "../bulletproofs_amd/csrc/fq29.h"
 using namespace bp;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -149,6 +150,53 @@ __global__ void __launch_bounds__(256) k_point(uint32_t* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the same chains on nine 29-bit limbs (fq29.h).  op 0: fe29_mul  1: fe29_sqr
+template <int OP>
+__global__ void __launch_bounds__(256) k_field29(uint32_t* out, int iters) {
+  fe29 a = fe29_from_u256(seed_fe(threadIdx.x + blockIdx.x * blockDim.x)), b = fe29_from_u256(seed_fe(threadIdx.x * 7 + 1));
+  for (int it = 0; it < iters; it++) {
+    if (OP == 0) { a = fe29_mul(a, b); b = fe29_mul(b, a); }
+    if (OP == 1) { a = fe29_sqr(a); b = fe29_sqr(b); }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < 9; i++) s ^= a.v[i] ^ b.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_point29(uint32_t* out, int iters) {
+  affine g = affine_gen();
+  u256 k = seed_fe(threadIdx.x + blockIdx.x * blockDim.x + 1);
+  k.v[7] = 0; k.v[6] = 0; k.v[5] = 0; k.v[4] = 0; k.v[3] = 0; k.v[2] = 0; k.v[1] = 0; k.v[0] = (k.v[0] & 0xffff) + 2;
+  xyzz29 acc = xyzz29_from(xyzz_mul_affine(g, k));  // distinct per lane
+  for (int it = 0; it < iters; it++) acc = xyzz29_madd(acc, g, (it & 1) != 0);
+  xyzz r = xyzz29_to(acc);
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= r.X.v[i] ^ r.Y.v[i] ^ r.ZZ.v[i] ^ r.ZZZ.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// reference for k_point29's result: the same alternating chain through ec.h
+__global__ void __launch_bounds__(256) k_point_alt(uint32_t* out, int iters) {
+  affine g = affine_gen();
+  u256 k = seed_fe(threadIdx.x + blockIdx.x * blockDim.x + 1);
+  k.v[7] = 0; k.v[6] = 0; k.v[5] = 0; k.v[4] = 0; k.v[3] = 0; k.v[2] = 0; k.v[1] = 0; k.v[0] = (k.v[0] & 0xffff) + 2;
+  xyzz acc = xyzz_mul_affine(g, k);
+  for (int it = 0; it < iters; it++) acc = xyzz_madd(acc, (it & 1) ? affine_neg(g) : g);
+  affine a = xyzz_to_affine(acc);
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= a.x.v[i] ^ a.y.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_point29_aff(uint32_t* out, int iters) {
+  affine g = affine_gen();
+  u256 k = seed_fe(threadIdx.x + blockIdx.x * blockDim.x + 1);
+  k.v[7] = 0; k.v[6] = 0; k.v[5] = 0; k.v[4] = 0; k.v[3] = 0; k.v[2] = 0; k.v[1] = 0; k.v[0] = (k.v[0] & 0xffff) + 2;
+  xyzz29 acc = xyzz29_from(xyzz_mul_affine(g, k));
+  for (int it = 0; it < iters; it++) acc = xyzz29_madd(acc, g, (it & 1) != 0);
+  affine a = xyzz_to_affine(xyzz29_to(acc));
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= a.x.v[i] ^ a.y.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <class F>
 static double time_ms(F launch, int reps = 3) {
   hipEvent_t e0, e1;
@@ -204,6 +252,31 @@ int main(int argc, char** argv) {
       printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"Gop_per_s\": %.3f, \"us_per_wave_op\": %.2f}\n", name, wps, n / ms / 1e6, ms * 1e3 / iters); }
     PT("xyzz_madd", 0) PT("xyzz_dbl", 1) PT("xyzz_add", 2)
 #undef PT
+    { double ms = time_ms([&] { hipLaunchKernelGGL(k_point29, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, iters); });
+      double n = (double)blocks * threads * iters;
+      printf("{\"bench\": \"xyzz29_madd\", \"waves_per_simd\": %d, \"Gop_per_s\": %.3f, \"us_per_wave_op\": %.2f}\n", wps, n / ms / 1e6, ms * 1e3 / iters); }
+  }
+  for (int wps = 1; wps <= 8; wps *= 2) {
+    int blocks = cus * wps;
+    const int iters = 2000;
+#define FLD29(name, OP) { double ms = time_ms([&] { hipLaunchKernelGGL((k_field29<OP>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, iters); }); \
+      double n = (double)blocks * threads * iters * 2; \
+      printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"Gop_per_s\": %.2f, \"ns_per_wave_op\": %.1f}\n", name, wps, n / ms / 1e6, ms * 1e6 / (iters * 2.0)); }
+    FLD29("fe29_mul", 0) FLD29("fe29_sqr", 1)
+#undef FLD29
+  }
+  {  // parity of the lazy chain against ec.h: same alternating +-G chain, affine results compared lane by lane
+    const int blocks = 8, iters = 37;
+    uint32_t *a, *b;
+    CK(hipMalloc(&a, blocks * 256 * 4)); CK(hipMalloc(&b, blocks * 256 * 4));
+    hipLaunchKernelGGL(k_point_alt, dim3(blocks), dim3(256), 0, 0, a, iters);
+    hipLaunchKernelGGL(k_point29_aff, dim3(blocks), dim3(256), 0, 0, b, iters);
+    std::vector<uint32_t> ha(blocks * 256), hb(blocks * 256);
+    CK(hipMemcpy(ha.data(), a, ha.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hb.data(), b, hb.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < ha.size(); i++) bad += ha[i] != hb[i];
+    printf("{\"check\": \"xyzz29_madd chain == xyzz_madd chain\", \"lanes\": %zu, \"mismatches\": %zu}\n", ha.size(), bad);
   }
   return 0;
 }

@@ -12,6 +12,7 @@
 #include "engine.h"
 #include "devio.h"
 #include "fixedbase.h"
+#include "fq29.h"
 #include "msm_core.h"
 #include "prover.h"
 
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(256) k_fb_msm_terms(uint32_t nterms, uint32_t 
   __shared__ uint32_t sdig[DW * 256];  // the lane's digit words, read back by window index
   const uint32_t msm = blockIdx.y, gt = blockIdx.x * 256u + threadIdx.x;
   const uint32_t t = gt >> lpt_log, sub = gt & ((1u << lpt_log) - 1u), lpt = 1u << lpt_log;
-  xyzz acc = xyzz_inf();
+  xyzz29 acc = xyzz29_inf();
   if (t < nterms) {
     u256 k = ld_u256(scalars + ((size_t)msm * nterms + t) * 32);
     if (!u256_is_zero(k)) {
@@ -45,11 +46,11 @@ __global__ void __launch_bounds__(256) k_fb_msm_terms(uint32_t nterms, uint32_t 
         bool neg;
         uint32_t mag = fb_decode<WB>(code, neg);
         affine q = ld_affine(table + (row0 + (size_t)w * E + (mag - 1)) * 64);
-        bucket_add(acc, q, neg);
+        acc = xyzz29_madd(acc, q, neg);
       }
     }
   }
-  xyzz s = block_sum(acc, red);
+  xyzz s = block_sum(xyzz29_to(acc), red);
   if (threadIdx.x == 0) st_xyzz(&partial[(size_t)msm * gridDim.x + blockIdx.x], s);
 }
 

@@ -19,6 +19,7 @@
 #include <mutex>
 #include "engine.h"
 #include "devio.h"
+#include "fq29.h"
 #include "glv.h"
 
 namespace bp {
@@ -136,6 +137,14 @@ __global__ void __launch_bounds__(256) k_rank_top(uint32_t ne, MsmPlan pl, const
   }
 }
 
+// the same in two steps, so that a loop can issue the load, do its arithmetic, and apply the endomorphism afterwards
+__device__ __forceinline__ affine entry_load(const uint8_t* __restrict__ points, uint32_t e, uint32_t glv) {
+  uint32_t idx = e & ~MSM_NEG;
+  return ld_affine(points + (size_t)(glv ? idx >> 1 : idx) * 64);
+}
+__device__ __forceinline__ affine entry_finish(const affine& raw, uint32_t e, uint32_t glv) {
+  return (glv && (e & 1u)) ? glv_phi(raw) : raw;
+}
 // point of a sorted entry: plain index, or (index >> 1, endomorphism flag) in GLV form
 __device__ __forceinline__ affine entry_point(const uint8_t* __restrict__ points, uint32_t e, uint32_t glv) {
   uint32_t idx = e & ~MSM_NEG;
@@ -425,22 +434,30 @@ __device__ __forceinline__ void light_lane(uint32_t t, const uint8_t* __restrict
   uint32_t cnt = hist[bid];
   points += (size_t)(bid / nb) * shift_stride;
   if (cnt > (uint32_t)LIGHT_MAX) return;  // heavy path owns it
-  xyzz acc = xyzz_inf();
+  // the bucket's sum on nine 29-bit limbs (fq29.h): started from the first point, one lazy mixed addition per further
+  // point; input points may be O, which the lazy formula does not take
+  xyzz29 acc = xyzz29_inf();
   if (cnt) {
     const uint32_t* lst = sorted + offs[bid];
     uint32_t e = lst[0];
     affine p = entry_point(points, e, glv);
-    for (uint32_t k = 0; k < cnt; k++) {
-      affine cur = p;
-      uint32_t ecur = e;
-      if (k + 1 < cnt) {  // prefetch the next point behind the arithmetic
+    acc = xyzz29_from_affine(p, (e & MSM_NEG) != 0);
+    affine raw = p;
+    if (cnt > 1) {
+      e = lst[1];
+      raw = entry_load(points, e, glv);
+    }
+    for (uint32_t k = 1; k < cnt; k++) {
+      const affine cur = entry_finish(raw, e, glv);
+      const uint32_t ecur = e;
+      if (k + 1 < cnt) {  // the next point's load is in flight during the addition; its endomorphism waits for the next step
         e = lst[k + 1];
-        p = entry_point(points, e, glv);
+        raw = entry_load(points, e, glv);
       }
-      bucket_add(acc, cur, (ecur & MSM_NEG) != 0);
+      if (!affine_is_inf(cur)) acc = xyzz29_madd(acc, cur, (ecur & MSM_NEG) != 0);
     }
   }
-  st_xyzz(&buckets[bid], acc);
+  st_xyzz(&buckets[bid], xyzz29_to(acc));
 }
 
 // ---- 5b. heavy buckets -----------------------------------------------------------------

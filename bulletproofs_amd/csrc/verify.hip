@@ -21,6 +21,7 @@
 #include "dec.h"
 #include "devio.h"
 #include "fixedbase.h"
+#include "fq29.h"
 #include "glv.h"
 #include "host_inv.h"
 #include "verify.h"
@@ -227,49 +228,69 @@ __global__ void __launch_bounds__(256) k_fixed_multiexp(uint32_t B, uint32_t nte
   if (live) {
     // The lpp lanes of a proof share its nterms x W (term, window) digits round-robin: lane `sub` takes the
     // flat indices sub, sub + lpp, ... (splitting by whole terms left up to lpp - 1 term slots idle per launch).
-    // The digit and the table row of the next index are fetched before the current mixed add.
     const uint32_t nf = nterms * (uint32_t)W;
-    auto fetch = [&](uint32_t f, uint32_t& code, size_t& row) {
-      uint32_t term = f / (uint32_t)W, w = f - term * (uint32_t)W;
-      uint32_t g = w / (uint32_t)PER, b = w - g * (uint32_t)PER;
-      uint32_t word = dig[((size_t)term * DW + g) * B + p];
-      code = SLOT == 32 ? word : ((word >> ((SLOT * b) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
-      row = ((size_t)term_base[term] * W + w) * E;
+    // Four stages in flight per lane.  For the lane's indices i0 < i1 < i2 < i3 (stride lpp), one loop step
+    //   loads the digit word and table base of i3 (their arithmetic waits for the next step),
+    //   decodes i2 (address of its table entry),
+    //   gathers the entry of i1 (decoded one step ago), and
+    //   adds the entry of i0 (gathered one step ago).
+    // Every load is unconditional and feeds nothing in its own step, so the waits land behind the mixed addition.
+    // (Touching the entry of i2 ahead of its gather - an atomic add of zero, no destination register - was measured:
+    // the extra random accesses cost more than the shorter waits save, 6.22 -> 7.16 ms per launch.)
+    auto fetch = [&](uint32_t fi, uint32_t& word, uint32_t& tb) {  // loads only; fi < nf
+      uint32_t term = fi / (uint32_t)W, w = fi - term * (uint32_t)W;
+      word = dig[((size_t)term * DW + w / (uint32_t)PER) * B + p];
+      tb = term_base[term];
     };
-    affine p0 = affine_inf(), p1 = affine_inf();  // fetched, not yet added (two gathers in flight)
-    bool n0 = false, n1 = false;
-    int cnt = 0;
-    uint32_t f = sub, code_next = 0;
-    size_t row_next = 0;
-    if (f < nf) fetch(f, code_next, row_next);
-#pragma unroll 1
-    while (f < nf) {
-      uint32_t code = code_next;
-      size_t row = row_next;
-      f += lpp;
-      if (f < nf) fetch(f, code_next, row_next);
-      if (code == 0) continue;
-      bool neg;
-      uint32_t mag = fb_decode<WB>(code, neg);
-      affine q = ld_affine(table + (row + (mag - 1)) * 64);
-      if (cnt == 2) {
-        bucket_add(acc, p0, n0);
-        p0 = p1;
-        n0 = n1;
-        p1 = q;
-        n1 = neg;
-      } else if (cnt == 1) {
-        p1 = q;
-        n1 = neg;
-        cnt = 2;
-      } else {
-        p0 = q;
-        n0 = neg;
-        cnt = 1;
-      }
+    struct Dec {
+      const uint8_t* addr;
+      bool neg, have;
+    };
+    auto decode = [&](uint32_t fi, uint32_t word, uint32_t tb) {  // fi < nf
+      const uint32_t term = fi / (uint32_t)W, w = fi - term * (uint32_t)W, b = w % (uint32_t)PER;
+      const uint32_t code = SLOT == 32 ? word : ((word >> ((SLOT * b) & 31)) & (uint32_t)((1ull << SLOT) - 1ull));
+      Dec d;
+      d.neg = false;
+      uint32_t mag = 1;
+      d.have = code != 0;
+      if (d.have) mag = fb_decode<WB>(code, d.neg);
+      d.addr = table + (((size_t)tb * W + w) * E + (mag - 1)) * 64;  // a zero digit reads a valid entry and drops it
+      return d;
+    };
+    affine p0 = affine_inf();  // gathered, not yet added
+    bool n0 = false, have0 = false;
+    uint32_t f = sub, word_next = 0, tb_next = 0;
+    Dec cur;
+    cur.addr = table;
+    cur.neg = false;
+    cur.have = false;
+    if (f < nf) {
+      fetch(f, word_next, tb_next);
+      cur = decode(f, word_next, tb_next);
+      fetch(f + lpp < nf ? f + lpp : nf - 1, word_next, tb_next);
     }
-    if (cnt >= 1) bucket_add(acc, p0, n0);
-    if (cnt == 2) bucket_add(acc, p1, n1);
+    // the accumulator lives on nine 29-bit limbs (fq29.h); ONE addition site
+    xyzz29 acc29 = xyzz29_inf();
+#pragma unroll 1
+    while (f < nf || have0) {
+      const bool in_range = f < nf;
+      // gather the current index's entry (a drain step re-reads the last one and drops it)
+      const affine qn = ld_affine(cur.addr);
+      const bool negn = cur.neg, have = in_range && cur.have;
+      // decode the next index; load the raw digits of the one after
+      const uint32_t f1 = f + lpp < nf ? f + lpp : nf - 1, f2 = f + 2 * lpp < nf ? f + 2 * lpp : nf - 1;
+      const Dec nxt = decode(f1, word_next, tb_next);
+      fetch(f2, word_next, tb_next);
+      // add the entry gathered in the previous step
+      if (have0) acc29 = xyzz29_madd(acc29, p0, n0);
+      // the new entry becomes the pending one
+      p0 = qn;
+      n0 = negn;
+      have0 = have;
+      cur = nxt;
+      if (in_range) f += lpp;
+    }
+    acc = xyzz29_to(acc29);
   }
   for (uint32_t dlt = lpp >> 1; dlt > 0; dlt >>= 1) {
     xyzz o = shfl_down_xyzz(acc, dlt);
@@ -288,7 +309,7 @@ __global__ void __launch_bounds__(256) k_fixed_flat(uint32_t B, uint32_t nterms,
   constexpr int W = fb_windows(WB), E = fb_entries(WB), DW = fb_dwords(WB), SLOT = fb_slot_bits(WB), PER = 32 / SLOT;
   __shared__ xyzz red[4];
   const uint32_t p = blockIdx.y, nf = nterms * (uint32_t)W;
-  xyzz acc = xyzz_inf();
+  xyzz29 acc = xyzz29_inf();
 #pragma unroll 1
   for (uint32_t f = blockIdx.x * 256u + threadIdx.x; f < nf; f += gridDim.x * 256u) {
     const uint32_t term = f / (uint32_t)W, w = f - term * (uint32_t)W;
@@ -297,9 +318,9 @@ __global__ void __launch_bounds__(256) k_fixed_flat(uint32_t B, uint32_t nterms,
     if (code == 0) continue;
     bool neg;
     uint32_t mag = fb_decode<WB>(code, neg);
-    bucket_add(acc, ld_affine(table + (((size_t)term_base[term] * W + w) * E + (mag - 1)) * 64), neg);
+    acc = xyzz29_madd(acc, ld_affine(table + (((size_t)term_base[term] * W + w) * E + (mag - 1)) * 64), neg);
   }
-  xyzz sum = block_sum(acc, red);
+  xyzz sum = block_sum(xyzz29_to(acc), red);
   if (threadIdx.x == 0) st_xyzz(gridDim.x == 1 ? &acc_out[p] : &part[(size_t)p * gridDim.x + blockIdx.x], sum);
 }
 __global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk /* <= 64 */, const xyzz* __restrict__ part, xyzz* __restrict__ acc_out) {

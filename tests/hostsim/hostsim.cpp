@@ -157,6 +157,37 @@ extern "C" void hs_glv_bit_lanes(const uint8_t* k, const uint8_t* pt, uint8_t* o
   sta(out, xyzz_to_affine(acc));
 }
 
+// ---- 29-bit-limb base field and the lazy mixed addition of the accumulation loops (fq29.h) ----
+#include "../../bulletproofs_amd/csrc/fq29.h"
+// op 0: a*b  1: a^2  2: a*b + c*d  3: round trip; operands canonical, result canonical
+extern "C" void hs_fe29_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, uint8_t* out) {
+  fe29 x = fe29_from_u256(ld(a)), y = fe29_from_u256(ld(b)), r;
+  switch (op) {
+    case 0: r = fe29_mul(x, y); break;
+    case 1: r = fe29_sqr(x); break;
+    case 2: r = fe29_mul2(x, y, fe29_from_u256(ld(c)), fe29_from_u256(ld(d))); break;
+    default: r = x; break;
+  }
+  st(out, fq_canon(fe29_to_u256(r)));
+}
+// lazy operands at the documented bounds: (a + (64p - c)) * norm(b + (64p - c)) + (64p - a) * b, and
+// norm(a + (64p - b))^2 + (128p - (b + 2c))  -> canonical
+extern "C" void hs_fe29_lazy(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out, uint8_t* out2) {
+  fe29 x = fe29_from_u256(ld(a)), y = fe29_from_u256(ld(b)), z = fe29_from_u256(ld(c));
+  fe29 l = fe29_add(x, fe29_neg(z));
+  fe29 r = fe29_norm(fe29_add(y, fe29_neg(z)));
+  st(out, fq_canon(fe29_to_u256(fe29_mul2(r, l, fe29_neg(x), y))));
+  fe29 w;
+  for (int i = 0; i < 9; i++) w.v[i] = y.v[i] + (z.v[i] << 1);
+  st(out2, fq_canon(fe29_to_u256(fe29_sqr_add(fe29_norm(fe29_add(x, fe29_neg(y))), fe29_neg2(w)))));
+}
+// sum of n points (+- by neg[i]) accumulated from the identity with xyzz29_madd
+extern "C" void hs_madd29_chain(const uint8_t* pts, const uint8_t* neg, size_t n, uint8_t* out) {
+  xyzz29 acc = xyzz29_from(xyzz_inf());
+  for (size_t i = 0; i < n; i++) acc = xyzz29_madd(acc, lda(pts + i * 64), neg[i] != 0);
+  sta(out, xyzz_to_affine(xyzz29_to(acc)));
+}
+
 // ---- host-side inversion of the latency paths (host_inv.h) ----
 #include "../../bulletproofs_amd/csrc/host_inv.h"
 // which: 0 = 1/a mod p (weak input allowed), 1 = x^-1 mod r through the Montgomery-form wrapper, 2 = host Fr4 fr_inv

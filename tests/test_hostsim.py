@@ -195,6 +195,61 @@ def test_glv_bit_lanes(hs):
     assert dp(out.raw) is None
 
 
+def test_fe29_field_ops(hs):
+    """fq29.h: nine 29-bit limbs with lazy additions; products, squares, two-product reductions and lazy operands at
+    the documented limb bounds against Python integers, edge values included."""
+    rng = random.Random(80)
+    edge = [0, 1, 2, P - 1, P - 2, 2**255, 2**256 % P, (1 << 29) - 1, ((1 << 261) - 1) % P, 0x1FFFFFFF << 174,
+            sum(0x1FFFFFFF << (29 * i) for i in range(0, 9, 2)) % P]
+    vals = edge + [rng.randrange(P) for _ in range(200)]
+    out = ctypes.create_string_buffer(32)
+    for i, a in enumerate(vals):
+        c2, d2 = vals[(i * 7 + 3) % len(vals)], vals[(i * 11 + 5) % len(vals)]
+        for bb in (vals[(i * 5 + 1) % len(vals)], P - 1, 0):
+            hs.hs_fe29_op(0, b(a), b(bb), b(0), b(0), out)
+            assert int.from_bytes(out.raw, "little") == a * bb % P
+            hs.hs_fe29_op(2, b(a), b(bb), b(c2), b(d2), out)
+            assert int.from_bytes(out.raw, "little") == (a * bb + c2 * d2) % P
+            out2 = ctypes.create_string_buffer(32)
+            hs.hs_fe29_lazy(b(a), b(bb), b(c2), out, out2)
+            assert int.from_bytes(out.raw, "little") == ((a - c2) * (bb - c2) - a * bb) % P
+            assert int.from_bytes(out2.raw, "little") == ((a - bb) ** 2 - bb - 2 * c2) % P
+        hs.hs_fe29_op(1, b(a), b(0), b(0), b(0), out)
+        assert int.from_bytes(out.raw, "little") == a * a % P
+        hs.hs_fe29_op(3, b(a), b(0), b(0), b(0), out)
+        assert int.from_bytes(out.raw, "little") == a
+
+
+def test_madd29_chain_is_the_group_sum(hs):
+    """xyzz29_madd (fq29.h): sums of table-like points from the identity equal the oracle's sum, through the cases the
+    lazy formula cannot do itself and hands to ec.h: identity accumulator, P + P, P + (-P), then going on from O."""
+    rng = random.Random(81)
+    G = o.GEN
+    pts = [o.point_mul(G, rng.randrange(1, R)) for _ in range(12)]
+
+    def run(seq):
+        raw = b"".join(pb(p) for p, _ in seq)
+        neg = bytes(1 if n else 0 for _, n in seq)
+        out = ctypes.create_string_buffer(64)
+        hs.hs_madd29_chain(raw, neg, len(seq), out)
+        exp = None
+        for p, n in seq:
+            exp = o.point_add(exp, o.point_neg(p) if n else p)
+        assert dp(out.raw) == exp
+
+    run([(p, False) for p in pts])
+    run([(p, i % 3 == 0) for i, p in enumerate(pts)])
+    A, B2 = pts[0], pts[1]
+    run([(A, False), (A, False)])                       # doubling
+    run([(A, False), (A, True)])                        # to the identity
+    run([(A, False), (A, True), (B2, False)])           # and on from it
+    run([(A, False), (A, False), (A, False), (A, True), (A, True), (A, True), (B2, True)])
+    run([(A, True), (B2, False), (o.point_add(o.point_neg(A), B2), True), (pts[2], False)])
+    for _ in range(20):
+        seq = [(rng.choice(pts[:4]), rng.random() < 0.5) for _ in range(rng.randrange(1, 40))]
+        run(seq)
+
+
 def test_host_side_inversions(hs):
     """host_inv.h / host_fr.h: the binary extended Euclid the verifiers' latency paths run on the CPU (x_r^-1 mod r,
     1/ZZZ mod p), against Python's modular inverse; 0 maps to 0, weakly reduced base-field inputs are accepted."""
