@@ -653,6 +653,34 @@ BP_HD xyzz29 xyzz29_inf() {
   return r;
 }
 
+// 2 p (dbl-2008-s-1 with a = 0) on lazy limbs:
+//   U = 2Y, V = U^2, W = U V, S = X V, M = 3 X^2, X3 = M^2 - 2S, Y3 = M (S - X3) - W Y, ZZ3 = V ZZ, ZZZ3 = W ZZZ
+// as 4 products, 2 squares, one square-and-add, one two-product reduction and one normalisation.  The identity
+// (ZZ = 0) stays the identity: ZZ3 = V * 0; secp256k1 has no point with Y = 0.
+BP_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
+  fe29 U;                                                     // 2Y < 2^30.001
+#pragma unroll
+  for (int i = 0; i < 9; i++) U.v[i] = p.Y.v[i] << 1;
+  const fe29 V = fe29_sqr(U);                                 // cross terms 4 x 2^31 x 2^30 + 2^60: fits
+  const fe29 W = fe29_mul(U, V);
+  const fe29 S = fe29_mul(p.X, V);
+  const fe29 XX = fe29_sqr(p.X);
+  fe29 M;                                                     // 3 X^2 < 2^30.6 -> N
+#pragma unroll
+  for (int i = 0; i < 9; i++) M.v[i] = XX.v[i] * 3u;
+  M = fe29_norm(M);
+  fe29 S2;
+#pragma unroll
+  for (int i = 0; i < 9; i++) S2.v[i] = S.v[i] << 1;
+  xyzz29 r;
+  r.X = fe29_sqr_add(M, fe29_neg2(S2));                       // M^2 + (128 p - 2S)
+  const fe29 T = fe29_add(S, fe29_neg(r.X));                  // L
+  r.Y = fe29_mul2(M, T, W, fe29_neg(p.Y));                    // M (S - X3) + W (64 p - Y)
+  r.ZZ = fe29_mul(V, p.ZZ);
+  r.ZZZ = fe29_mul(W, p.ZZZ);
+  return r;
+}
+
 // (x, +-y, 1, 1), or the identity for q = O
 BP_HD xyzz29 xyzz29_from_affine(const affine& q, bool negate) {
   if (affine_is_inf(q)) return xyzz29_inf();

@@ -10,6 +10,7 @@
 // The group element computed is exactly k*P (+ ...); only the evaluation order differs.
 #pragma once
 #include "ec.h"
+#include "fq29.h"
 
 namespace bp {
 
@@ -221,6 +222,31 @@ BP_HD xyzz xyzz_phi(const xyzz& p) {  // (beta X, Y, ZZ, ZZZ); the identity stay
   r.X = fq_mul(p.X, glv_const(BETA));
   return r;
 }
+// The same chain with the accumulator on nine 29-bit limbs (fq29.h): lazy doubling and mixed addition, one addition
+// site; the table load is unconditional (index 0 re-reads entry 1 and drops it) so that nothing waits for it before the
+// step's arithmetic has been issued.
+template <class LoadAff>
+BP_HD xyzz glv_pair_multiexp_tab29(const u256& k0, const u256& k1, LoadAff load) {
+  GlvPos s0 = glv_split_pos(k0), s1 = glv_split_pos(k1);
+  BitReg b0 = bitreg_init5(s0.m1), b1 = bitreg_init5(s0.m2), b2 = bitreg_init5(s1.m1), b3 = bitreg_init5(s1.m2);
+  auto next_idx = [&]() -> uint32_t {
+    return bitreg_next(b0) | (bitreg_next(b1) << 1) | (bitreg_next(b2) << 2) | (bitreg_next(b3) << 3);
+  };
+  xyzz29 acc = xyzz29_inf();
+  uint32_t idx = next_idx();
+  affine q = load((int)(idx ? idx : 1u));
+#pragma unroll 1
+  for (int i = 0; i < GLV_BITS; i++) {
+    const affine cur = q;
+    const uint32_t icur = idx;
+    idx = i + 1 < GLV_BITS ? next_idx() : 0u;
+    q = load((int)(idx ? idx : 1u));
+    acc = xyzz29_dbl(acc);
+    if (icur && !affine_is_inf(cur)) acc = xyzz29_madd(acc, cur, false);
+  }
+  return xyzz29_to(acc);
+}
+
 // ---- k*P with one lane per bit -------------------------------------------------------------------------------
 // Lane j < GLV_LANE_BITS holds Tj = 2^j P (XYZZ) and contributes [bit j of |k1|] (+-Tj) + [bit j of |k2|] (+-phi(Tj)),
 // k = k1 + k2*lambda the signed split: no doubling and at most one addition per lane, and the lanes' terms add up

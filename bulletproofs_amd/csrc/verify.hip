@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     stm(xk_m, (size_t)round * B + p, x2);  // mkOtherExponents needs the squares only (Verifier.hs:66-71)
     stm(xkinv_m, (size_t)round * B + p, xinv);
     const uint8_t* T = rtab + ((size_t)round * 15 * B + p) * 64;
-    acc = glv_pair_multiexp_tab(Fr::from_mont(x2), Fr::from_mont(Fr::sqr(xinv)),
+    acc = glv_pair_multiexp_tab29(Fr::from_mont(x2), Fr::from_mont(Fr::sqr(xinv)),
                                 [&](int e) { return ld_affine(T + (size_t)(e - 1) * B * 64); });
     acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
   }

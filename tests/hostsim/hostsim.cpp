@@ -206,6 +206,20 @@ extern "C" void hs_xyzz_to_affine_host(const uint8_t* xyzz128, uint8_t* out) {
   sta(out, bp::host::xyzz_to_affine_host(p));
 }
 
+// the same through the 29-bit-limb chain (glv_pair_multiexp_tab29)
+extern "C" void hs_glv_pair_tab29(const uint8_t* ks, const uint8_t* ps, uint8_t* out) {
+  affine tab[16];
+  glv_pair_table_local(lda(ps), lda(ps + 64), tab);
+  xyzz r = glv_pair_multiexp_tab29(ld(ks), ld(ks + 32), [&](int e) { return tab[e]; });
+  sta(out, xyzz_to_affine(r));
+}
+// n doublings of a point on lazy limbs
+extern "C" void hs_dbl29_chain(const uint8_t* pt, int n, uint8_t* out) {
+  xyzz29 acc = xyzz29_from_affine(lda(pt), false);
+  for (int i = 0; i < n; i++) acc = xyzz29_dbl(acc);
+  sta(out, xyzz_to_affine(xyzz29_to(acc)));
+}
+
 // ---- device decimal formatter (dec.h): 80-byte record of a 32-byte LE integer ----
 #include "../../bulletproofs_amd/csrc/dec.h"
 extern "C" void hs_dec_record(const uint8_t* le, uint8_t* rec80) {

@@ -177,6 +177,14 @@ def test_glv_positive_split_and_pair_table(hs):
             out = ctypes.create_string_buffer(64)
             hs.hs_glv_pair_tab(b(k0) + b(k1), pb(p0) + pb(p1), out)
             assert dp(out.raw) == o.add_two_mul_p(k0, p0, k1, p1)
+            hs.hs_glv_pair_tab29(b(k0) + b(k1), pb(p0) + pb(p1), out)     # the 29-bit-limb chain of k_round
+            assert dp(out.raw) == o.add_two_mul_p(k0, p0, k1, p1)
+    for n in (1, 2, 5, 130):
+        out = ctypes.create_string_buffer(64)
+        hs.hs_dbl29_chain(pb(A), n, out)
+        assert dp(out.raw) == o.point_mul(A, 2**n % R)
+    hs.hs_dbl29_chain(pb(None), 3, out)
+    assert dp(out.raw) is None
 
 
 def test_glv_bit_lanes(hs):
