@@ -681,6 +681,38 @@ BP_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
   return r;
 }
 
+// p + q for two XYZZ points (add-2008-s) on lazy limbs; P + P, P - P and identities make ZZ3 = 0 and go to ec.h
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__
+#else
+inline
+#endif
+xyzz29 xyzz29_add_exact(xyzz29 p, xyzz29 q) {
+  return xyzz29_from(xyzz_add(xyzz29_to(p), xyzz29_to(q)));
+}
+BP_HD xyzz29 xyzz29_add(const xyzz29& p, const xyzz29& q) {
+  const fe29 U1 = fe29_mul(p.X, q.ZZ), U2 = fe29_mul(q.X, p.ZZ);
+  const fe29 S1 = fe29_mul(p.Y, q.ZZZ), S2 = fe29_mul(q.Y, p.ZZZ);
+  const fe29 nS1 = fe29_neg(S1);
+  const fe29 Pd = fe29_norm(fe29_add(U2, fe29_neg(U1)));
+  const fe29 Rd = fe29_norm(fe29_add(S2, nS1));
+  const fe29 PP = fe29_sqr(Pd);
+  const fe29 PPP = fe29_mul(Pd, PP);
+  const fe29 Q = fe29_mul(U1, PP);
+  fe29 W;
+#pragma unroll
+  for (int i = 0; i < 9; i++) W.v[i] = PPP.v[i] + (Q.v[i] << 1);
+  xyzz29 r;
+  r.X = fe29_sqr_add(Rd, fe29_neg2(W));
+  const fe29 T = fe29_add(Q, fe29_neg(r.X));
+  r.Y = fe29_mul2(Rd, T, nS1, PPP);
+  r.ZZ = fe29_mul(fe29_mul(p.ZZ, q.ZZ), PP);
+  r.ZZZ = fe29_mul(fe29_mul(p.ZZZ, q.ZZZ), PPP);
+  const uint32_t l6 = r.ZZ.v[6], l7 = r.ZZ.v[7];
+  if (l6 == l7 && (l6 == 0u || l6 == M29)) return xyzz29_add_exact(p, q);
+  return r;
+}
+
 // (x, +-y, 1, 1), or the identity for q = O
 BP_HD xyzz29 xyzz29_from_affine(const affine& q, bool negate) {
   if (affine_is_inf(q)) return xyzz29_inf();

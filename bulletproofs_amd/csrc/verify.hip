@@ -351,19 +351,22 @@ __device__ __forceinline__ xyzz glv_multiexp_dev(const u256 (&k)[NP], const affi
   if constexpr (NP >= 3) h2 = glv_prep_point(k[2], P[2], 1, 2, store1);
   joint_table_composites<(NP >= 2 ? 4 : 2)>(store0, load0);
   if constexpr (NP >= 3) joint_table_composites<2>(store1, load1);
-  xyzz acc = xyzz_inf();
+  // the chain on nine 29-bit limbs (fq29.h): lazy doubling, lazy full addition of the XYZZ table entries; ONE addition
+  // site serves both tables
+  xyzz29 acc = xyzz29_inf();
 #pragma unroll 1
   for (int i = 0; i < GLV_BITS; i++) {
     uint32_t idx0 = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1), idx1 = 0;
     if constexpr (NP >= 2) idx0 |= (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
     if constexpr (NP >= 3) idx1 = bitreg_next(h2.a) | (bitreg_next(h2.b) << 1);
-    acc = xyzz_dbl(acc);
-    if (idx0) acc = xyzz_add(acc, load0((int)idx0));
-    if constexpr (NP >= 3) {
-      if (idx1) acc = xyzz_add(acc, load1((int)idx1));
+    acc = xyzz29_dbl(acc);
+#pragma unroll 1
+    for (int t = 0; t < (NP >= 3 ? 2 : 1); t++) {
+      const uint32_t idx = t ? idx1 : idx0;
+      if (idx) acc = xyzz29_add(acc, xyzz29_from(t ? load1((int)idx) : load0((int)idx)));
     }
   }
-  return acc;
+  return xyzz29_to(acc);
 }
 
 // stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported)

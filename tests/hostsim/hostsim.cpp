@@ -213,6 +213,15 @@ extern "C" void hs_glv_pair_tab29(const uint8_t* ks, const uint8_t* ps, uint8_t*
   xyzz r = glv_pair_multiexp_tab29(ld(ks), ld(ks + 32), [&](int e) { return tab[e]; });
   sta(out, xyzz_to_affine(r));
 }
+// sum of n points by full XYZZ additions on lazy limbs (every point enters as k_i * P_i with small k_i so that Z != 1)
+extern "C" void hs_add29_chain(const uint8_t* pts, size_t n, uint8_t* out) {
+  xyzz29 acc = xyzz29_inf();
+  for (size_t i = 0; i < n; i++) {
+    xyzz29 q = xyzz29_dbl(xyzz29_dbl(xyzz29_from_affine(lda(pts + i * 64), false)));  // 4 P_i, projective
+    acc = xyzz29_add(acc, q);
+  }
+  sta(out, xyzz_to_affine(xyzz29_to(acc)));
+}
 // n doublings of a point on lazy limbs
 extern "C" void hs_dbl29_chain(const uint8_t* pt, int n, uint8_t* out) {
   xyzz29 acc = xyzz29_from_affine(lda(pt), false);

@@ -258,6 +258,21 @@ def test_madd29_chain_is_the_group_sum(hs):
         run(seq)
 
 
+def test_add29_full_addition(hs):
+    """xyzz29_add (fq29.h): full additions of projective points, with equal, opposite and identity operands."""
+    rng = random.Random(82)
+    pts = [o.point_mul(o.GEN, rng.randrange(1, R)) for _ in range(6)]
+    A = pts[0]
+    seqs = [pts, [A, A], [A, o.point_neg(A)], [A, o.point_neg(A), pts[1]], [None, A, None, A, pts[2]], [A, A, A, o.point_neg(A)]]
+    for seq in seqs:
+        out = ctypes.create_string_buffer(64)
+        hs.hs_add29_chain(b"".join(pb(p) for p in seq), len(seq), out)
+        exp = None
+        for p in seq:
+            exp = o.point_add(exp, o.point_mul(p, 4) if p else None)
+        assert dp(out.raw) == exp
+
+
 def test_host_side_inversions(hs):
     """host_inv.h / host_fr.h: the binary extended Euclid the verifiers' latency paths run on the CPU (x_r^-1 mod r,
     1/ZZZ mod p), against Python's modular inverse; 0 maps to 0, weakly reduced base-field inputs are accepted."""
