@@ -682,12 +682,7 @@ BP_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
 }
 
 // p + q for two XYZZ points (add-2008-s) on lazy limbs; P + P, P - P and identities make ZZ3 = 0 and go to ec.h
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __noinline__
-#else
-inline
-#endif
-xyzz29 xyzz29_add_exact(xyzz29 p, xyzz29 q) {
+BP_HD xyzz29 xyzz29_add_exact(const xyzz29& p, const xyzz29& q) {
   return xyzz29_from(xyzz_add(xyzz29_to(p), xyzz29_to(q)));
 }
 BP_HD xyzz29 xyzz29_add(const xyzz29& p, const xyzz29& q) {
@@ -725,14 +720,10 @@ BP_HD xyzz29 xyzz29_from_affine(const affine& q, bool negate) {
   return r;
 }
 
-// The cases the lazy formula cannot do (P + P, P - P, acc = O), through ec.h.  Rare: kept out of line so that every
-// accumulation loop carries one copy.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __noinline__
-#else
-inline
-#endif
-xyzz29 xyzz29_madd_exact(xyzz29 p, affine q, bool negate) {  // by value: a reference would pin the caller's accumulator in scratch memory
+// The cases the lazy formula cannot do (P + P, P - P, acc = O), through ec.h.  Rare, and INLINE on purpose: as an
+// out-of-line call it returned through memory, and the compiler then stored every fast-path result to the same
+// stack slot as well (36 dwords of scratch traffic per mixed addition, 2.3 GB per k_fixed_multiexp launch).
+BP_HD xyzz29 xyzz29_madd_exact(const xyzz29& p, const affine& q, bool negate) {
   affine qq = q;
   if (negate) qq = affine_neg(q);
   return xyzz29_from(xyzz_madd(xyzz29_to(p), qq));
