@@ -12,12 +12,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fe.h"
+#include "fq29.h"
 
 namespace bp {
 
 struct FqInvOps {
   static __device__ __forceinline__ u256 mul(const u256& a, const u256& b) { return fq_mul(a, b); }
-  static __device__ __forceinline__ u256 inv(const u256& a) { return fq_inv(a); }
+  static __device__ __forceinline__ u256 inv(const u256& a) { return fq_inv29(a); }  // Fermat chain on 29-bit limbs
   static __device__ __forceinline__ u256 one() { return u256_one(); }
   static __device__ __forceinline__ bool is_zero(const u256& a) { return fq_is_zero(a); }
 };

@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
   }
   const u256 zzz = live ? acc.ZZZ : u256_one();
-  u256 zi = BATCH_INV ? block_batch_inverse<FqInvOps>(zzz, inv_lds) : fq_inv(zzz);
+  u256 zi = BATCH_INV ? block_batch_inverse<FqInvOps>(zzz, inv_lds) : fq_inv29(zzz);
   affine out = affine_inf();
   if (live) {
     out = xyzz_to_affine_with_inv(acc, zi);

@@ -166,6 +166,7 @@ extern "C" void hs_fe29_op(int op, const uint8_t* a, const uint8_t* b, const uin
     case 0: r = fe29_mul(x, y); break;
     case 1: r = fe29_sqr(x); break;
     case 2: r = fe29_mul2(x, y, fe29_from_u256(ld(c)), fe29_from_u256(ld(d))); break;
+    case 4: st(out, fq_canon(fq_inv29(ld(a)))); return;
     default: r = x; break;
   }
   st(out, fq_canon(fe29_to_u256(r)));

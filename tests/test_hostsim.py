@@ -226,6 +226,8 @@ def test_fe29_field_ops(hs):
         assert int.from_bytes(out.raw, "little") == a * a % P
         hs.hs_fe29_op(3, b(a), b(0), b(0), b(0), out)
         assert int.from_bytes(out.raw, "little") == a
+        hs.hs_fe29_op(4, b(a), b(0), b(0), b(0), out)        # Fermat inversion on 29-bit limbs; 0 -> 0
+        assert int.from_bytes(out.raw, "little") == (pow(a, -1, P) if a % P else 0)
 
 
 def test_madd29_chain_is_the_group_sum(hs):
