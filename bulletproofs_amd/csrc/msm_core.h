@@ -106,7 +106,9 @@ BP_HD xyzz segment_value(const MsmPlan& pl, int sidx, const xyzz& S, const xyzz&
   if (sidx == 0) return T;
   int seg_log = 0;
   while ((1 << seg_log) < pl.seg) seg_log++;
-  xyzz m = xyzz_mul_small(S, (uint32_t)sidx, 16);
+  int idx_bits = 1;  // sidx < nseg
+  while ((1 << idx_bits) < pl.nseg) idx_bits++;
+  xyzz m = xyzz_mul_small(S, (uint32_t)sidx, idx_bits);
   for (int i = 0; i < seg_log; i++) m = xyzz_dbl(m);
   return xyzz_add(T, m);
 }
