@@ -21,6 +21,7 @@
 #include "devio.h"
 #include "fq29.h"
 #include "glv.h"
+#include "lanes29.h"
 
 namespace bp {
 
@@ -666,66 +667,10 @@ __global__ void __launch_bounds__(256) k_bucket_sum(const xyzz* __restrict__ bt,
 }
 // Horner over the window sums, sum_w 2^(c w) S_w: (W - 1) c DEPENDENT doublings in a single wave whose latency nothing
 // else hides (128 of them for 2^20 points: 0.8 ms of a 2.7 ms MSM on the 8 x 32 limbs of ec.h, one lane).  The chain runs
-// on the 29-bit limbs of fq29.h, and a doubling is spread over the four lanes of a quad so that its nine products become
-// three rounds of four independent ones:
-//   lane:       0 (holds Y)          1 (holds X)        2 (holds ZZZ)       3 (holds ZZ)
-//   round A     V = (2Y)^2           XX = X^2           -                   -
-//   round B     W = 2Y V             S = X V            MM = M M, M = 3 XX  ZZ3 = ZZ V
-//   round C     W (64 p - Y)         M (S - X3)         ZZZ3 = W ZZZ        -            X3 = MM - 2 S
-//   new state   Y3 = sum of lanes 0, 1                  X3                  ZZZ3         ZZ3
-// Operands travel by quad-permute DPP moves (no LDS); every lane runs the same instruction stream (the unused slots
-// multiply whatever they hold).  Same formula and limb classes as xyzz29_dbl: 2Y < 2^30.001 meets only class N
-// operands, the differences are normalised before they are multiplied.  The identity (all limbs zero) stays zero.
-// The W - 1 additions between the windows gather the point into every lane, add (xyzz29_add, all four lanes compute
-// the same sum) and spread it again.  msm_core.h's window_combine is the portable form of the same sum.
-template <int SRC>
-__device__ __forceinline__ fe29 quad_bcast(const fe29& v) {  // every lane reads lane SRC of its quad
-  fe29 r;
-#pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], SRC * 0x55, 0xF, 0xF, true);
-  return r;
-}
-__device__ __forceinline__ fe29 fe29_sel(bool c, const fe29& a, const fe29& b) {
-  fe29 r;
-#pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = c ? a.v[i] : b.v[i];
-  return r;
-}
-__device__ __forceinline__ fe29 quad_spread(const xyzz29& p, uint32_t lane) {
-  return fe29_sel(lane == 0, p.Y, fe29_sel(lane == 1, p.X, fe29_sel(lane == 2, p.ZZZ, p.ZZ)));
-}
-__device__ __forceinline__ xyzz29 quad_gather(const fe29& P) {
-  xyzz29 r;
-  r.Y = quad_bcast<0>(P);
-  r.X = quad_bcast<1>(P);
-  r.ZZZ = quad_bcast<2>(P);
-  r.ZZ = quad_bcast<3>(P);
-  return r;
-}
-__device__ __forceinline__ fe29 quad_dbl(const fe29& P, uint32_t lane) {
-  const uint32_t sh = lane == 0 ? 1u : 0u;
-  fe29 A;  // lane 0: U = 2Y; the others: their own coordinate
-#pragma unroll
-  for (int i = 0; i < 9; i++) A.v[i] = P.v[i] << sh;
-  const fe29 Q1 = fe29_sqr(A);  // lane 0: V, lane 1: XX
-  const fe29 V = quad_bcast<0>(Q1);
-  fe29 M = quad_bcast<1>(Q1);
-#pragma unroll
-  for (int i = 0; i < 9; i++) M.v[i] *= 3u;  // < 2^30.6
-  M = fe29_norm(M);
-  const bool l2 = lane == 2;
-  const fe29 Q2 = fe29_mul(fe29_sel(l2, M, A), fe29_sel(l2, M, V));  // W | S | MM | ZZ3
-  const fe29 W = quad_bcast<0>(Q2), S = quad_bcast<1>(Q2), MM = quad_bcast<2>(Q2);
-  fe29 S2;
-#pragma unroll
-  for (int i = 0; i < 9; i++) S2.v[i] = S.v[i] << 1;
-  const fe29 X3 = fe29_norm(fe29_add(MM, fe29_neg2(S2)));  // M^2 + (128 p - 2S)
-  const fe29 T = fe29_add(S, fe29_neg(X3));               // S - X3, lazy
-  const bool l1 = lane == 1;
-  const fe29 Q3 = fe29_mul(fe29_sel(l1, M, W), fe29_sel(l1, T, fe29_sel(lane == 0, fe29_neg(P), P)));  // -WY | MT | ZZZ3 | -
-  const fe29 Y3 = fe29_norm(fe29_add(Q3, quad_bcast<1>(Q3)));  // lane 0: M (S - X3) - W Y
-  return fe29_sel(lane == 0, Y3, fe29_sel(l1, X3, fe29_sel(l2, Q3, Q2)));
-}
+// on the 29-bit limbs of fq29.h, and a doubling is spread over the four lanes of a quad (lanes29.h: three rounds of
+// independent products instead of nine dependent ones).  The W - 1 additions between the windows gather the point into
+// every lane, add (xyzz29_add, all four lanes compute the same sum) and spread it again.  msm_core.h's window_combine is
+// the portable form of the same sum.
 // called by the first four lanes of a wave; lane 0 stores
 template <class LoadW>
 __device__ __forceinline__ void window_combine_store(const MsmPlan& pl, LoadW load, uint8_t* out_affine, xyzz* out_xyzz) {

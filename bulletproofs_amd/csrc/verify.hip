@@ -22,6 +22,7 @@
 #include "devio.h"
 #include "fixedbase.h"
 #include "fq29.h"
+#include "lanes29.h"
 #include "glv.h"
 #include "host_inv.h"
 #include "verify.h"
@@ -508,6 +509,111 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     if (host_out) st_affine(host_out + (size_t)p * 64, out);
   }
   if (host_txt) block_store_point_text(lds, out, host_txt, d.B);
+}
+
+// The same round with the 129-step chain of every proof spread over a PAIR of lanes (lanes29.h): a doubling and a mixed
+// addition are 5 + 5 rounds of two independent products instead of 9 + 10 dependent ones, which is what the host waits
+// for six times per chunk.  A workgroup of 256 lanes serves 128 proofs: lanes 0..127 (two waves) do the scalar work of
+// one proof each (x^2, x^-1, the GLV halves), hand the half-scalars to the pairs through LDS, all 256 lanes run the
+// chains, and lanes 0..127 take the sums back for the running commitment, its affine form and its text.  The other two
+// waves skip the scalar parts as whole waves, so those cost no more instructions than in k_round.
+constexpr uint32_t RP_PROOFS = 128;
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_round_pair(VDims d, uint32_t round, const uint8_t* __restrict__ xk /*[B][32] canonical*/, u256* __restrict__ xk_m,
+             u256* __restrict__ xkinv_m, const uint8_t* __restrict__ rtab, uint8_t* __restrict__ acc_aff,
+             uint8_t* __restrict__ host_out, uint8_t* __restrict__ host_txt) {
+  __shared__ uint32_t lds[256 * 2 * DEC_REC_WORDS];
+  __shared__ uint32_t xch[RP_PROOFS * 36];  // per proof: 4 x 5 half-scalar words on the way in, X, Y, ZZ, ZZZ on the way out
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t tid = threadIdx.x, first = blockIdx.x * RP_PROOFS;
+  const uint32_t p = first + tid;
+  const bool solo = tid < RP_PROOFS, live = solo && p < d.B;
+  const size_t B = d.B;
+  if (solo) {  // whole waves
+    u256 x = Fr::one();
+    if (live) x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
+    const u256 xinv = Fr::inv(x);
+    GlvPos s0, s1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) s0.m1[i] = s0.m2[i] = s1.m1[i] = s1.m2[i] = 0;
+    if (live) {
+      const u256 x2 = Fr::sqr(x);
+      stm(xk_m, (size_t)round * B + p, x2);
+      stm(xkinv_m, (size_t)round * B + p, xinv);
+      s0 = glv_split_pos(Fr::from_mont(x2));
+      s1 = glv_split_pos(Fr::from_mont(Fr::sqr(xinv)));
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      xch[tid * 36 + i] = s0.m1[i];
+      xch[tid * 36 + 5 + i] = s0.m2[i];
+      xch[tid * 36 + 10 + i] = s1.m1[i];
+      xch[tid * 36 + 15 + i] = s1.m2[i];
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t q = tid >> 1, pq = first + q;
+    const bool odd = (tid & 1u) != 0;
+    uint32_t m[4][5];
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+#pragma unroll
+      for (int i = 0; i < 5; i++) m[h][i] = xch[q * 36 + h * 5 + i];
+    __syncthreads();  // every pair has its half-scalars: the area is free for the results
+    pair29 acc;
+    acc.c0 = fe29_zero();
+    acc.c1 = fe29_zero();
+    if (pq < d.B) {  // both lanes of a pair agree
+      BitReg b0 = bitreg_init5(m[0]), b1 = bitreg_init5(m[1]), b2 = bitreg_init5(m[2]), b3 = bitreg_init5(m[3]);
+      const uint8_t* T = rtab + ((size_t)round * 15 * B + pq) * 64;
+#pragma unroll 1
+      for (int i = 0; i < GLV_BITS; i++) {
+        const uint32_t idx = bitreg_next(b0) | (bitreg_next(b1) << 1) | (bitreg_next(b2) << 2) | (bitreg_next(b3) << 3);
+        acc = pair_dbl(acc, odd);
+        if (idx) acc = pair_madd(acc, T + (size_t)(idx - 1) * B * 64, odd);
+      }
+    }
+    // X, Y, ZZ, ZZZ of proof q at xch[36 q + 0 / 9 / 18 / 27]
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      xch[q * 36 + (odd ? 0 : 9) + i] = acc.c0.v[i];
+      xch[q * 36 + (odd ? 18 : 27) + i] = acc.c1.v[i];
+    }
+  }
+  __syncthreads();
+  affine out = affine_inf();
+  if (live) {
+    xyzz29 a29;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      a29.X.v[i] = xch[tid * 36 + i];
+      a29.Y.v[i] = xch[tid * 36 + 9 + i];
+      a29.ZZ.v[i] = xch[tid * 36 + 18 + i];
+      a29.ZZZ.v[i] = xch[tid * 36 + 27 + i];
+    }
+    xyzz acc = xyzz_madd(xyzz29_to(a29), ld_affine(acc_aff + (size_t)p * 64));
+    out = xyzz_to_affine_with_inv(acc, fq_inv29(acc.ZZZ));
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  }
+  if (host_txt) {  // uniform: every lane of the workgroup arrives; lanes 128.. hold empty records
+    uint32_t w[2 * DEC_REC_WORDS];
+#pragma unroll
+    for (int j = 0; j < 2 * DEC_REC_WORDS; j++) w[j] = 0;
+    if (solo) {
+      uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
+      u256_to_dec_record(out.x, wx);
+      u256_to_dec_record(out.y, wy);
+#pragma unroll
+      for (int j = 0; j < DEC_REC_WORDS; j++) {
+        w[j] = wx[j];
+        w[DEC_REC_WORDS + j] = wy[j];
+      }
+    }
+    const uint32_t valid = d.B - first < RP_PROOFS ? d.B - first : RP_PROOFS;
+    block_store_records<2 * DEC_REC_WORDS>(lds, w, host_txt + (size_t)first * 2 * DEC_REC, valid);
+  }
 }
 
 // ---- small batches: the latency path ------------------------------------------------------------------------
@@ -1006,7 +1112,16 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
     vb->stage++;
     return BP_OK;
   }
-  if (round_batch)
+  // Two lanes per proof (k_round_pair) shorten the chain the host waits for but issue about a third more instructions:
+  // a gain while the GPU has idle issue slots (1,024 proofs 8.7 -> 7.4 ms per pass, 8,192 11.2 -> 9.9, 32,768 in four
+  // chunks 16.6 -> 15.9), a loss once the chunks of a large batch fill it (65,536 in four chunks 25.1 -> 26.1 ms).
+  // BP_ROUND_PAIR=0 / 1 forces one form.
+  static const int pair_env = getenv("BP_ROUND_PAIR") ? atoi(getenv("BP_ROUND_PAIR")) : -1;
+  const bool round_pair = pair_env < 0 ? B <= 8192 : pair_env != 0;
+  if (round_pair && !round_batch)
+    hipLaunchKernelGGL(k_round_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, vb->stream, d, round,
+                       xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct, vb->direct_host ? out_text : nullptr);
+  else if (round_batch)
     hipLaunchKernelGGL(k_round<true>, VB_GRID(B), d, round, xin, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, direct,
                        vb->direct_host ? out_text : nullptr);
   else
