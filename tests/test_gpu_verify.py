@@ -51,8 +51,11 @@ def run_batch(eng, n, m2, proofs, vcommits, check_trace=True):
     us = [o.shamir_u(p["tBlinding"], p["mu"], p["t"]) for p in proofs]
     chal = _lib.enc_scalars(ys) + _lib.enc_scalars(zs) + _lib.enc_scalars(xs) + _lib.enc_scalars(us)
     acc = _lib.dec_points(vb.begin(chal), B)
-    if check_trace:
-        for i, p in enumerate(proofs):
+    # check_trace: True (every proof), False, or the indices to compare with the oracle
+    traced = range(B) if check_trace is True else (check_trace or ())
+    if traced:
+        for i in traced:
+            p = proofs[i]
             hsp = o.hs_prime(ys[i], n * m2)
             exp = o.compute_lr_commitment(n, m2, p["aCommit"], p["sCommit"], p["t"], p["tBlinding"], p["mu"],
                                           xs[i], ys[i], zs[i], hsp)
@@ -61,8 +64,9 @@ def run_batch(eng, n, m2, proofs, vcommits, check_trace=True):
         xk = [o.shamir_x_prime(acc[i], p["productProof"]["lCommits"][r], p["productProof"]["rCommits"][r])
               for i, p in enumerate(proofs)]
         new = _lib.dec_points(vb.round(r, _lib.enc_scalars(xk)), B)
-        if check_trace:
-            for i, p in enumerate(proofs):
+        if traced:
+            for i in traced:
+                p = proofs[i]
                 li, ri = p["productProof"]["lCommits"][r], p["productProof"]["rCommits"][r]
                 xi = pow(xk[i], -1, R)
                 exp = o.point_add(o.point_add(o.point_mul(li, xk[i] * xk[i] % R), o.point_mul(ri, xi * xi % R)), acc[i])
@@ -111,6 +115,50 @@ def test_state_machine_vs_oracle(eng_gens, n, m):
     exp = [o.mrp_verify_proof(2**n, v, p) for p, v in zip(all_p, all_v)]
     assert exp[:3] == [True] * 3
     assert got == exp
+
+
+def degenerate_lr(pr, kind, r):
+    """A copy of the proof whose round-r commitments hit the group law's special cases."""
+    ipp = dict(pr["productProof"])
+    L, Rr = list(ipp["lCommits"]), list(ipp["rCommits"])
+    if kind == 0:
+        L[r] = None                       # L = O: identity entries in the round's joint table
+    elif kind == 1:
+        Rr[r] = None
+    elif kind == 2:
+        Rr[r] = L[r]                      # L + R is a doubling; the chain meets acc == entry
+    elif kind == 3:
+        Rr[r] = o.point_neg(L[r])         # L + R = O
+    else:
+        L[r] = Rr[r] = None
+    ipp["lCommits"], ipp["rCommits"] = L, Rr
+    return dict(pr, productProof=ipp)
+
+
+@pytest.mark.parametrize("copies", [1, 500])
+def test_round_kernels_special_cases(eng_gens, copies):
+    """The one-lane-per-proof path is only taken by batches of more than 16 proofs (two lanes per proof up to 8,192
+    proofs, one lane above): every round's accumulator against the oracle for honest proofs and for proofs whose
+    L_r / R_r are O, equal or opposite (the exceptional cases of the mixed addition inside the chains)."""
+    n, rng = 8, random.Random(77)
+    base = []
+    for _ in range(2):
+        v, b = rng.randrange(0, 2**n), rng.randrange(1, R)
+        base.append((o.mrp_generate_proof(2**n, [(v, b)], *o.draw_blinders(rng, n)), [o.commit(v, b)]))
+    proofs = [p for p, _ in base]
+    vcs = [v for _, v in base]
+    for kind in range(5):
+        for r in range(3):
+            src = base[(kind + r) % 2]
+            proofs.append(degenerate_lr(src[0], kind, r))
+            vcs.append(src[1])
+    nb = len(proofs)
+    assert nb > 16
+    exp = [o.mrp_verify_proof(2**n, v, p) for p, v in zip(proofs, vcs)]
+    assert exp[:2] == [True, True]
+    got = run_batch(eng_gens, n, 1, proofs * copies, vcs * copies,
+                    check_trace=list(range(nb)) + list(range(nb * (copies - 1), nb * copies)))
+    assert got == exp * copies
 
 
 def test_bench_proof_golden(eng_gens):
