@@ -124,17 +124,17 @@ def cpu_baseline(sc, pts, n_bits, sample, gpu_verdicts):
 # ---- config 3: MSM ----------------------------------------------------------------------------------------------
 def msm_choose_c(n):
     """msm_core.h msm_choose_c."""
-    for lim, c in ((32, 4), (128, 5), (512, 7), (2048, 8), (8192, 10), (32768, 11), (131072, 13)):
+    for lim, c in ((16384, 13), (131072, 14)):
         if n < lim:
             return c
     return 16
 
 
-def msm_algorithmic_mads(n_local, direct_max=65536):
+def msm_algorithmic_mads(n_local, direct_max=0):
     """SURVEY.md 8(d) accounting for the path a local MSM of n_local terms takes.  Bucket method with GLV halves:
     every point enters twice with a 129-bit half-scalar, W = ceil(130 / c) windows of c bits:
     modmuls = 2 n W 10 (bucket accumulation) + W 2^(c-1) 2 14 (running-sum reduction) + 128 10 (window doublings).
-    Direct path (n <= 65,536): one 129-step GLV double-and-add per term."""
+    Direct path (only behind BP_MSM_DIRECT_MAX since the bucket tail runs on quads): one 129-step GLV chain per term."""
     if n_local <= direct_max:
         mm = n_local * (GLV_BITS * MODMUL_PER_DBL + GLV_BITS * 0.75 * MODMUL_PER_MADD)
         return mm * MADS_PER_MODMUL, dict(path="direct", steps=GLV_BITS)

@@ -11,6 +11,7 @@
 //   pair  (2 lanes, doubling + mixed addition; verify.hip k_round_pair):  5 + 5 rounds instead of 9 + 10, for only
 //         ~1/3 more instructions in total (the quad form would be 3 + 4 rounds for more than twice the instructions)
 #pragma once
+#include "devio.h"
 #include "fq29.h"
 
 namespace bp {
@@ -82,6 +83,50 @@ __device__ __forceinline__ fe29 quad_dbl(const fe29& P, uint32_t lane) {
   const fe29 Q3 = fe29_mul(fe29_sel(l1, M, W), fe29_sel(l1, T, fe29_sel(lane == 0, fe29_neg(P), P)));  // -WY | MT | ZZZ3 | -
   const fe29 Y3 = fe29_norm(fe29_add(Q3, quad_bcast<1>(Q3)));  // lane 0: M (S - X3) - W Y
   return fe29_sel(lane == 0, Y3, fe29_sel(l1, X3, fe29_sel(l2, Q3, Q2)));
+}
+
+// p + q for two XYZZ points, both spread over the quad (add-2008-s; 12 products and 2 squares in four rounds):
+//   lane:       0 (Y)                1 (X)              2 (ZZZ)             3 (ZZ)
+//   round A     S1 = Y1 ZZZ2         U1 = X1 ZZ2        S2 = Y2 ZZZ1        U2 = X2 ZZ1    R = S2 - S1, P = U2 - U1
+//   round B     RR = R^2             PP = P^2           ZZZ1 ZZZ2           ZZ1 ZZ2
+//   round C     PPP = P PP           Q = U1 PP          PPP                 ZZ3 = ZZ1 ZZ2 PP
+//   round D     PPP (64 p - S1)      R (Q - X3)         ZZZ3 = ZZZ1 ZZZ2 PPP  -            X3 = RR - PPP - 2Q
+//   new state   Y3 = sum of lanes 0, 1                  X3                  ZZZ3           ZZ3
+// ZZ3 = 0 (mod p) - equal or opposite points, an identity on either side - goes to the exact routine of ec.h.
+__device__ __forceinline__ fe29 quad_add(const fe29& pc, const fe29& qc, uint32_t lane) {
+  const bool lo = lane < 2, even = (lane & 1u) == 0, l0 = lane == 0, l1 = lane == 1;
+  fe29 qx, Q1x;
+#pragma unroll
+  for (int i = 0; i < 9; i++) qx.v[i] = dpp_quad<0x4E>(qc.v[i]);  // quad_perm [2, 3, 0, 1]: ZZZ2 | ZZ2 | Y2 | X2
+  const fe29 Q1 = fe29_mul(pc, qx);                               // S1 | U1 | S2 | U2
+#pragma unroll
+  for (int i = 0; i < 9; i++) Q1x.v[i] = dpp_quad<0x4E>(Q1.v[i]);  // S2 | U2 | S1 | U1
+  const fe29 D = fe29_norm(fe29_add(fe29_sel(lo, Q1x, Q1), fe29_neg(fe29_sel(lo, Q1, Q1x))));  // R | P | R | P
+  const fe29 Q2 = fe29_mul(fe29_sel(lo, D, pc), fe29_sel(lo, D, qc));                           // RR | PP | ZZZ12 | ZZ12
+  const fe29 PP = quad_bcast<1>(Q2), Pd = quad_bcast<1>(D);
+  const fe29 Q3 = fe29_mul(fe29_sel(even, Pd, fe29_sel(l1, Q1, Q2)), PP);                       // PPP | Q | PPP | ZZ3
+  const uint32_t l6 = Q3.v[6], l7 = Q3.v[7];
+  const uint32_t mine = lane == 3 && l6 == l7 && (l6 == 0u || l6 == M29) ? 1u : 0u;
+  if (dpp_quad<3 * 0x55>(mine) != 0u)
+    return quad_spread(xyzz29_add_exact(quad_gather(pc), quad_gather(qc)), lane);
+  const fe29 RR = quad_bcast<0>(Q2), PPP = quad_bcast<0>(Q3), Q = quad_bcast<1>(Q3);
+  fe29 W;  // PPP + 2Q < 2^30.6
+#pragma unroll
+  for (int i = 0; i < 9; i++) W.v[i] = PPP.v[i] + (Q.v[i] << 1);
+  const fe29 X3 = fe29_norm(fe29_add(RR, fe29_neg2(W)));
+  const fe29 T = fe29_add(Q, fe29_neg(X3));  // lazy
+  const fe29 Rb = quad_bcast<0>(D);
+  const fe29 Q4 = fe29_mul(fe29_sel(l0, fe29_neg(Q1), fe29_sel(l1, Rb, Q2)), fe29_sel(l1, T, Q3));  // -S1 PPP | R T | ZZZ3 | -
+  const fe29 Y3 = fe29_norm(fe29_add(Q4, quad_bcast<1>(Q4)));
+  return fe29_sel(l0, Y3, fe29_sel(l1, X3, fe29_sel(lane == 2, Q4, Q3)));
+}
+// the lane's coordinate of an XYZZ point in memory (8 x 32 limbs, weakly reduced): Y | X | ZZZ | ZZ
+__device__ __forceinline__ uint32_t quad_coord_offset(uint32_t lane) { return lane == 0 ? 32u : lane == 1 ? 0u : lane == 2 ? 96u : 64u; }
+__device__ __forceinline__ fe29 quad_load(const xyzz* p, uint32_t lane) {
+  return fe29_from_u256(ld_u256((const char*)p + quad_coord_offset(lane)));
+}
+__device__ __forceinline__ void quad_store(xyzz* p, const fe29& v, uint32_t lane) {
+  st_u256((char*)p + quad_coord_offset(lane), fe29_to_u256(v));
 }
 
 // ---- pair: the even lane holds (Y, ZZZ), the odd lane (X, ZZ) --------------------------------------------------------

@@ -627,6 +627,45 @@ __global__ void __launch_bounds__(256) k_window_sum(const xyzz* __restrict__ seg
   if (threadIdx.x == 0) st_xyzz(&wsum[w], acc);
 }
 
+// ---- 7q. window sums with every point spread over a quad of lanes (lanes29.h) -----------------------------------------
+// A quad does an addition in 4 rounds of products instead of 14, on the 29-bit limbs (4.3 us against 6.4 us at one wave
+// per SIMD); each lane loads and stores only its own coordinate.  (The segment step in the same form was measured too:
+// four times the lanes put two waves on every SIMD and the kernel took the same 0.23 ms, so it stays one lane per
+// segment.)
+// out[w][g] = sum of slice g of in[w][0..n): one workgroup of 256 lanes (64 quads, one wave per SIMD: two waves on a SIMD
+// would halve each chain's speed) per (slice, window); strided partial sums, then a tree over the quads through LDS.
+// Called twice: segment values -> WSQ_GROUPS partial sums per window -> the window sums.
+constexpr uint32_t WSQ_GROUPS = 16;
+__global__ void __launch_bounds__(256) k_window_sum_quad(const xyzz* __restrict__ in, uint32_t n, uint32_t groups,
+                                                        xyzz* __restrict__ out) {
+  __shared__ uint32_t tree[64 * 4 * 9];
+  const uint32_t q = threadIdx.x >> 2, lane = threadIdx.x & 3u, g = blockIdx.x, w = blockIdx.y;
+  const uint32_t per = (n + groups - 1) / groups, lo = g * per, hi = lo + per < n ? lo + per : n;
+  const uint32_t cnt = hi > lo ? (hi - lo < 64u ? hi - lo : 64u) : 0u;  // quads that hold a value
+  fe29 acc = fe29_zero();
+  bool have = false;
+#pragma unroll 1
+  for (uint32_t s = lo + q; s < hi; s += 64u) {
+    const fe29 v = quad_load(&in[(size_t)w * n + s], lane);
+    acc = have ? quad_add(acc, v, lane) : v;
+    have = true;
+  }
+#pragma unroll 1
+  for (uint32_t m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) tree[(q * 4 + lane) * 9 + i] = acc.v[i];
+    __syncthreads();
+    if (q < m && q + m < cnt) {
+      fe29 o;
+#pragma unroll
+      for (int i = 0; i < 9; i++) o.v[i] = tree[((q + m) * 4 + lane) * 9 + i];
+      acc = quad_add(acc, o, lane);
+    }
+    __syncthreads();
+  }
+  if (q == 0) quad_store(&out[(size_t)w * groups + g], acc, lane);  // an empty slice stores the identity (all zero)
+}
+
 // ---- 6'/7'. the same weighted sums by suffix scans (nb <= 65,536) -------------------------------------------------
 // sum_b (b + 1) B[b] = sum_b suffix(b), suffix(b) = sum_{b' >= b} B[b'].  A workgroup scans 256 buckets (8 additions
 // deep) and sums its suffixes (8 more): tb = sum_t (t + 1) B[256 blk + t] and the workgroup total bt.  Then
@@ -771,10 +810,13 @@ __global__ void __launch_bounds__(1024) k_direct_reduce(const xyzz* __restrict__
   }
 }
 
-static size_t msm_direct_max() {
+// longest term list of the one-chain-per-term kernels (msm_direct_multi: up to four sums in ONE launch, which is what
+// the provers' L / R pairs want), and the size up to which a SINGLE sum takes that form (BP_MSM_DIRECT_MAX, default never)
+static size_t msm_direct_max() { return 65536; }
+static size_t msm_single_direct_max() {
   static const size_t v = [] {
     const char* e = getenv("BP_MSM_DIRECT_MAX");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)65536;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
   }();
   return v;
 }
@@ -855,9 +897,13 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     ctx->err = "bp_msm: n must be below 2^27";
     return BP_ERR_ARG;
   }
-  if (!prep && c_override <= 0 && n <= msm_direct_max()) {
+  // One GLV double-and-add chain per term (k_direct_terms): since the bucket method's tail runs on quads of lanes it is
+  // no longer the faster form at any size (1.5-1.65 ms for every n <= 65,536 against 0.70-0.99 ms).  It
+  // remains for a static scratch array too small for the buckets (bp_msm_dev_static) and behind BP_MSM_DIRECT_MAX.
+  auto run_direct = [&]() -> int {
     uint32_t nblk = (uint32_t)((n + 255) / 256);
-    if ((rc = msm_ws_get(ctx, wsrc, (size_t)nblk * sizeof(xyzz), &ws)) != BP_OK) return rc;
+    int rc2;
+    if ((rc2 = msm_ws_get(ctx, wsrc, (size_t)nblk * sizeof(xyzz), &ws)) != BP_OK) return rc2;
     xyzz* partial = (xyzz*)ws;
     SegN sn = {{(uint32_t)n, 0, 0, 0}};
     hipLaunchKernelGGL(k_direct_terms, dim3(nblk), dim3(256), 0, st, (const uint8_t*)d_scalars, (const uint8_t*)d_points,
@@ -866,7 +912,9 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
                        (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
     BP_TRY(hipGetLastError());
     return BP_OK;
-  }
+  };
+  const bool may_direct = !prep && c_override <= 0 && n <= msm_direct_max();
+  if (may_direct && n <= msm_single_direct_max()) return run_direct();
   int c = prep ? prep->c : (c_override > 0 ? c_override : msm_choose_c(n));
   if (c < 1 || c > 16) {
     ctx->err = "bp_msm: window_bits must be in 1..16";
@@ -912,11 +960,12 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
       const size_t seg_vals = (size_t)pl.W * pl.nseg;
       segv = cv.take<xyzz>(seg_vals > scan_vals ? seg_vals : scan_vals);
     }
-    wsum = cv.take<xyzz>((size_t)2 * pl.W);
+    wsum = cv.take<xyzz>((size_t)(1 + WSQ_GROUPS) * pl.W);  // W sums (2 W for k_bucket_sum) + the quad tail's partial sums
     (void)zero_end;
     return cv.off;
   };
   size_t need = carve(nullptr);
+  if (may_direct && wsrc.fixed && need > wsrc.fixed_bytes) return run_direct();
   if ((rc = msm_ws_get(ctx, wsrc, need, &ws)) != BP_OK) return rc;
   carve(ws);
   size_t zero_bytes = (size_t)((char*)(chist + CO_MAXCNT) - (char*)hist);
@@ -1025,7 +1074,16 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   }
   uint32_t nsegt = (uint32_t)pl.W * pl.nseg;
   hipLaunchKernelGGL(k_seg_reduce, dim3((nsegt + 255) / 256), dim3(256), 0, st, buckets, pl, segv);
-  hipLaunchKernelGGL(k_window_sum, dim3(pl.W), dim3(256), 0, st, segv, pl, wsum);
+  // window sums: 16 slices per window by quads, then the 16 partial sums (0.04 ms against 0.22 ms for one workgroup of
+  // single lanes per window).  BP_MSM_QUAD=0 keeps the one-lane kernel.
+  static const bool tail_quad = !(getenv("BP_MSM_QUAD") && atoi(getenv("BP_MSM_QUAD")) == 0);
+  if (tail_quad && pl.nseg >= 64) {
+    xyzz* part = wsum + pl.W;  // [W][WSQ_GROUPS]: wsum is carved with room behind the W sums
+    hipLaunchKernelGGL(k_window_sum_quad, dim3(WSQ_GROUPS, pl.W), dim3(256), 0, st, segv, (uint32_t)pl.nseg, WSQ_GROUPS, part);
+    hipLaunchKernelGGL(k_window_sum_quad, dim3(1, pl.W), dim3(256), 0, st, part, WSQ_GROUPS, 1u, wsum);
+  } else {
+    hipLaunchKernelGGL(k_window_sum, dim3(pl.W), dim3(256), 0, st, segv, pl, wsum);
+  }
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, wsum, pl, (uint8_t*)d_out_affine, (xyzz*)d_out_xyzz);
   BP_TRY(hipGetLastError());
   return BP_OK;

@@ -37,16 +37,17 @@ BP_HD MsmPlan msm_plan(int c, int bits = 256) {
   return p;
 }
 
-// Window size for N terms (measured sweet spots).
+// Window size for N terms, measured on MI355X (benchmarks/msm_bench.py --c; ms per sum, GLV halves, two-level sort):
+//   n          2^5   2^8   2^11  2^13  2^14  2^15  2^16  2^17
+//   c = 13     0.70  0.71  0.78  0.90  1.02  1.18  1.47
+//   c = 14                 0.87  0.93  0.95  0.96  0.99
+//   c = 16                             0.94  0.99  0.99  0.98      (2^18: 1.15, 2^20: 2.09)
+// Windows below 13 bits leave the two-level sort (FINE_BITS) and cost 0.9-2.9 ms at these sizes; fewer, wider windows
+// also shorten the Horner chain.  Narrow windows remain reachable through `window_bits`.
 inline int msm_choose_c(size_t n) {
-  if (n < 32) return 4;
-  if (n < 128) return 5;
-  if (n < 512) return 7;
-  if (n < 2048) return 8;
-  if (n < 8192) return 10;
-  if (n < 32768) return 11;
-  if (n < 131072) return 13;
-  return 16;  // measured on MI355X (benchmarks/msm_window_probe.py): 2^17 1.88 ms, 2^18 2.19 ms against 1.93 / 2.46 at c = 14
+  if (n < 16384) return 13;
+  if (n < 131072) return 14;
+  return 16;
 }
 
 constexpr uint32_t MSM_SKIP = 0xFFFFFFFFu;  // digit 0: no bucket
