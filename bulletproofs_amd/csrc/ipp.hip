@@ -85,10 +85,10 @@ __global__ void __launch_bounds__(64) k_bit_tables(const uint8_t* __restrict__ p
 // acc <- k0*p0 + k1*p1 + acc, p0 / p1 by their bit tables; 256 lanes, the result stays XYZZ (the host normalises)
 __global__ void __launch_bounds__(256) k_bits_lincomb2(const xyzz* __restrict__ sh0, const xyzz* __restrict__ sh1, u256 k0,
                                                       u256 k1, xyzz* __restrict__ acc) {
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
   xyzz term = bit_lane_term(side ? k1 : k0, side ? sh1 : sh0, j);
-  xyzz sum = block_sum(term, red);
+  xyzz sum = block_sum_quad(term, red);
   if (t == 0) st_xyzz(acc, xyzz_add(sum, ld_xyzz(acc)));
 }
 
@@ -99,7 +99,7 @@ struct BitSums {
 };
 __global__ void __launch_bounds__(256) k_bits_multiexp(const xyzz* __restrict__ sh, const uint8_t* __restrict__ scalars,
                                                       BitSums bs, xyzz* __restrict__ out) {
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
   const uint32_t first = bs.first[blockIdx.x], count = bs.count[blockIdx.x];
   xyzz acc = xyzz_inf();
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_bits_multiexp(const xyzz* __restrict__ 
     u256 k = Fr::reduce_once(ld_u256(scalars + (size_t)(first + term) * 32));
     acc = xyzz_add(acc, bit_lane_term(k, sh + (size_t)(first + term) * GLV_LANE_BITS, j));
   }
-  xyzz sum = block_sum(acc, red);
+  xyzz sum = block_sum_quad(acc, red);
   if (t == 0) st_xyzz(&out[blockIdx.x], sum);
 }
 

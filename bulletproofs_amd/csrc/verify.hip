@@ -681,11 +681,11 @@ __global__ void __launch_bounds__(64) k_vprep0_split(VDims d, const uint8_t* __r
 __global__ void __launch_bounds__(128) k_stage1_tail_bits(VDims d, const uint8_t* __restrict__ pts, const u256* __restrict__ cst,
                                                          const xyzz* __restrict__ acc1, const xyzz* __restrict__ sh,
                                                          xyzz* __restrict__ acc_x, xyzz* __restrict__ hx) {
-  __shared__ xyzz red[2];
+  __shared__ uint32_t red[128 * 36];
   const uint32_t p = blockIdx.x;
   const size_t B = d.B;
   xyzz term = bit_lane_term(Fr::from_mont(ldm(cst, C_X * B + p)), sh + sh_index(VP_S, B, p), (int)threadIdx.x);
-  xyzz sum = block_sum(term, red);
+  xyzz sum = block_sum_quad(term, red);
   if (threadIdx.x == 0) {
     sum = xyzz_add(sum, ld_xyzz(&acc1[p]));
     sum = xyzz_madd(sum, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(256) k_round_bits(VDims d, uint32_t round, con
                                                    const uint8_t* __restrict__ hinv, u256* __restrict__ xk_m,
                                                    u256* __restrict__ xkinv_m, const xyzz* __restrict__ sh,
                                                    xyzz* __restrict__ acc_x, xyzz* __restrict__ hx) {
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   const uint32_t p = blockIdx.x;
   const size_t B = d.B;
   const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
@@ -709,7 +709,7 @@ __global__ void __launch_bounds__(256) k_round_bits(VDims d, uint32_t round, con
   u256 x2 = Fr::sqr(x);
   u256 k = Fr::from_mont(side == 0 ? x2 : Fr::sqr(xinv));
   xyzz term = bit_lane_term(k, sh + sh_index(VP_L0 + (side ? d.k : 0) + round, B, p), j);
-  xyzz sum = block_sum(term, red);
+  xyzz sum = block_sum_quad(term, red);
   if (t == 0) {
     stm(xk_m, (size_t)round * B + p, x2);
     stm(xkinv_m, (size_t)round * B + p, xinv);
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(256) k_round_bits(VDims d, uint32_t round, con
 // lanes per proof: two terms per pass over the bit positions, one workgroup sum at the end
 __global__ void __launch_bounds__(256) k_tcheck_bits(VDims d, const uint8_t* __restrict__ vs, const xyzz* __restrict__ sh,
                                                     xyzz* __restrict__ acc2) {
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   const uint32_t p = blockIdx.x;
   const size_t B = d.B;
   const int t = (int)threadIdx.x, side = t >> 7, j = t & (GLV_LANE_BITS - 1);
@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(256) k_tcheck_bits(VDims d, const uint8_t* __r
     uint32_t row = term < d.m ? VP_L0 + 2 * d.k + term : (term == d.m ? VP_T1 : VP_T2);
     acc = xyzz_add(acc, bit_lane_term(ld_u256(vs + ((size_t)term * B + p) * 32), sh + sh_index(row, B, p), j));
   }
-  xyzz sum = block_sum(acc, red);
+  xyzz sum = block_sum_quad(acc, red);
   if (t == 0) st_xyzz(&acc2[p], xyzz_add(sum, ld_xyzz(&acc2[p])));
 }
 
