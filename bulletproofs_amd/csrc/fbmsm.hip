@@ -13,6 +13,7 @@
 #include "devio.h"
 #include "fixedbase.h"
 #include "fq29.h"
+#include "lanes29.h"
 #include "msm_core.h"
 #include "prover.h"
 
@@ -25,7 +26,7 @@ __global__ void __launch_bounds__(256) k_fb_msm_terms(uint32_t nterms, uint32_t 
                                                      const uint32_t* __restrict__ term_base, const uint8_t* __restrict__ table,
                                                      xyzz* __restrict__ partial /*[nmsm][gridDim.x]*/) {
   constexpr int W = fb_windows(WB), E = fb_entries(WB), DW = fb_dwords(WB), SLOT = fb_slot_bits(WB), PER = 32 / SLOT;
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   __shared__ uint32_t sdig[DW * 256];  // the lane's digit words, read back by window index
   const uint32_t msm = blockIdx.y, gt = blockIdx.x * 256u + threadIdx.x;
   const uint32_t t = gt >> lpt_log, sub = gt & ((1u << lpt_log) - 1u), lpt = 1u << lpt_log;
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) k_fb_msm_terms(uint32_t nterms, uint32_t 
       }
     }
   }
-  xyzz s = block_sum(xyzz29_to(acc), red);
+  xyzz s = block_sum_quad(xyzz29_to(acc), red);  // quads of lanes (lanes29.h): the sums are what a prover's round waits for
   if (threadIdx.x == 0) st_xyzz(&partial[(size_t)msm * gridDim.x + blockIdx.x], s);
 }
 
@@ -58,18 +59,11 @@ __global__ void __launch_bounds__(256) k_fb_msm_terms(uint32_t nterms, uint32_t 
 __global__ void __launch_bounds__(256) k_fb_msm_finish(uint32_t nblk, const xyzz* __restrict__ partial,
                                                       const uint8_t* __restrict__ offset /*64 B affine, or null*/,
                                                       xyzz* __restrict__ out /*[nmsm]*/) {
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   const uint32_t msm = blockIdx.x;
   xyzz acc = xyzz_inf(), s;
-  if (blockDim.x == 64) {
-    if (threadIdx.x < nblk) acc = ld_xyzz(&partial[(size_t)msm * nblk + threadIdx.x]);
-    int width = 1;
-    while (width < (int)nblk) width <<= 1;
-    s = wave_sum_width(acc, width);
-  } else {
-    for (uint32_t i = threadIdx.x; i < nblk; i += blockDim.x) acc = xyzz_add(acc, ld_xyzz(&partial[(size_t)msm * nblk + i]));
-    s = block_sum(acc, red);
-  }
+  for (uint32_t i = threadIdx.x; i < nblk; i += blockDim.x) acc = xyzz_add(acc, ld_xyzz(&partial[(size_t)msm * nblk + i]));
+  s = block_sum_quad(acc, red);  // 64 or 256 threads
   if (threadIdx.x == 0) {
     if (msm == 0 && offset) s = xyzz_madd(s, ld_affine(offset));
     st_xyzz(&out[msm], s);
