@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256) k_fixed_flat(uint32_t B, uint32_t nterms,
                                                    const uint32_t* __restrict__ term_base, const uint8_t* __restrict__ table,
                                                    xyzz* __restrict__ part /*[B][gridDim.x]*/, xyzz* __restrict__ acc_out) {
   constexpr int W = fb_windows(WB), E = fb_entries(WB), DW = fb_dwords(WB), SLOT = fb_slot_bits(WB), PER = 32 / SLOT;
-  __shared__ xyzz red[4];
+  __shared__ uint32_t red[256 * 36];
   const uint32_t p = blockIdx.y, nf = nterms * (uint32_t)W;
   xyzz29 acc = xyzz29_inf();
 #pragma unroll 1
@@ -321,16 +321,15 @@ __global__ void __launch_bounds__(256) k_fixed_flat(uint32_t B, uint32_t nterms,
     uint32_t mag = fb_decode<WB>(code, neg);
     acc = xyzz29_madd(acc, ld_affine(table + (((size_t)term_base[term] * W + w) * E + (mag - 1)) * 64), neg);
   }
-  xyzz sum = block_sum(xyzz29_to(acc), red);
+  xyzz sum = block_sum_quad(xyzz29_to(acc), red);
   if (threadIdx.x == 0) st_xyzz(gridDim.x == 1 ? &acc_out[p] : &part[(size_t)p * gridDim.x + blockIdx.x], sum);
 }
 __global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk /* <= 64 */, const xyzz* __restrict__ part, xyzz* __restrict__ acc_out) {
+  __shared__ uint32_t red[64 * 36];
   const uint32_t p = blockIdx.x;
   xyzz acc = xyzz_inf();
   if (threadIdx.x < nblk) acc = ld_xyzz(&part[(size_t)p * nblk + threadIdx.x]);
-  int width = 1;
-  while ((uint32_t)width < nblk) width <<= 1;
-  acc = wave_sum_width(acc, width);
+  acc = block_sum_quad(acc, red);
   if (threadIdx.x == 0) st_xyzz(&acc_out[p], acc);
 }
 
