@@ -181,7 +181,7 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     ch.first = first;
     ch.B = (uint32_t)(first + per <= batch ? per : batch - first);
     first += ch.B;
-    int rc = bp_vbatch_create(ctx, n_bits, m, ch.B, &ch.vb);
+    int rc = vbatch_create_ex(ctx, n_bits, m, ch.B, true, &ch.vb);
     if (rc != BP_OK) {
       bp_vjob_destroy(job);
       return rc;
@@ -209,6 +209,8 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     ch.acc_txt = cv.take<uint8_t>(B * 160);
     ch.lr_txt = cv.take<uint8_t>((size_t)2 * job->k * B * 160 + 16);
     ch.vb->direct_host = true;  // acc / verdict above are pinned: the kernels store to them directly
+    Pool* pool = job->pool;
+    ch.vb->pfor = [pool](size_t n, const std::function<void(size_t, size_t)>& f) { pool->run(f, n, 4); };
   }
   *out = job;
   return BP_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <functional>
 #include "engine.h"
 #include "fixedbase.h"
 
@@ -40,6 +41,9 @@ inline uint32_t vbatch_lpp(uint32_t B) {
 // Owns its stream and pinned staging so that two batches can ping-pong: the host
 // hashes one while the GPU works on the other.
 struct bp_vbatch {
+  // host loops over the proofs of the latency path (inversions between the hashes): the job's hashing threads when the
+  // batch belongs to a bp_vjob, the calling thread otherwise
+  std::function<void(size_t, const std::function<void(size_t, size_t)>&)> pfor;
   bp_ctx* ctx;
   bp::VDims d;
   bp::DevBuf buf;
@@ -95,6 +99,8 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
 int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
 int vbatch_wait(bp_vbatch* vb);
+// bp_vbatch_create with the caller's promise to set bp_vbatch::pfor (its threads run the latency path's host loops)
+int vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, bool pooled_host, bp_vbatch** out);
 // After vbatch_wait of a begin or round stage: the commitment as affine bytes in out_commitment ([B][64]).  Batches
 // on the latency path (vb->split) normalise on the host here; for the others the kernels have written it already.
 int vbatch_collect(bp_vbatch* vb, uint8_t* out_commitment);

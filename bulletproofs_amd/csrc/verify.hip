@@ -622,7 +622,25 @@ k_round_pair(VDims d, uint32_t round, const uint8_t* __restrict__ xk /*[B][32] c
 // product k * point is then one lane per bit (glv.h, glv_bit_lane: at most one addition) and a workgroup sum.
 // The field inversions of the path (y^-1, (y - 1)^-1, x_r^-1, and the normalisation of each running commitment)
 // are done by the host between its hashes, microseconds each against ~0.14 ms for one lane of the GPU.
-constexpr uint32_t VSPLIT_MAX_B = 16;
+// Measured (bench.py --batch, one chunk; ms per pass, this path against one lane / a pair of lanes per proof):
+//   16: 1.23   64: 1.68 / 6.74   128: 1.99 / 7.05   256: 2.65 / 7.00   512: 3.80 / 7.14   1,024: 6.45 / 7.39   2,048: 12.0 / 7.8
+// (the host's inversions run on the job's hashing threads; with one thread the paths cross near 100 proofs)
+constexpr uint32_t VSPLIT_MAX_B_DEFAULT = 768;
+constexpr uint32_t VSPLIT_SERIAL_MAX_B = 96;  // without lent threads (bp_vbatch_* called directly)
+static uint32_t vsplit_max_b() {  // BP_VSPLIT_MAX: largest batch that takes this path
+  static const uint32_t v = [] {
+    const char* e = getenv("BP_VSPLIT_MAX");
+    long x = e ? atol(e) : (long)VSPLIT_MAX_B_DEFAULT;
+    return (uint32_t)(x < 0 ? 0 : (x > 4096 ? 4096 : x));
+  }();
+  return v;
+}
+static void vbatch_host_for(bp_vbatch* vb, size_t n, const std::function<void(size_t, size_t)>& body) {
+  if (vb->pfor && n > 8)
+    vb->pfor(n, body);
+  else
+    body(0, n);
+}
 enum { HI_YINV = 0, HI_YM1INV = 1, HI_XINV = 2 };
 
 // bit-table index of row `row` (>= VP_S) of proof p
@@ -1028,14 +1046,16 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   uint8_t* direct = vb->direct_host ? out_commitment : nullptr;
   if (vb->split) {
     // the two inversions of this stage on the host (`challenges` is host memory in both modes)
-    for (size_t p = 0; p < B; p++) {
-      u256 y;
-      memcpy(&y, challenges + ((size_t)0 * B + p) * 32, 32);
-      y = Fr::to_mont(Fr::reduce_once(y));
-      u256 yi = host::fr_inv_mont_host(y), ym1i = host::fr_inv_mont_host(Fr::sub(y, Fr::one()));
-      memcpy(vb->hinv + ((size_t)HI_YINV * B + p) * 32, &yi, 32);
-      memcpy(vb->hinv + ((size_t)HI_YM1INV * B + p) * 32, &ym1i, 32);
-    }
+    vbatch_host_for(vb, B, [&](size_t p0, size_t p1) {
+      for (size_t p = p0; p < p1; p++) {
+        u256 y;
+        memcpy(&y, challenges + ((size_t)0 * B + p) * 32, 32);
+        y = Fr::to_mont(Fr::reduce_once(y));
+        u256 yi = host::fr_inv_mont_host(y), ym1i = host::fr_inv_mont_host(Fr::sub(y, Fr::one()));
+        memcpy(vb->hinv + ((size_t)HI_YINV * B + p) * 32, &yi, 32);
+        memcpy(vb->hinv + ((size_t)HI_YM1INV * B + p) * 32, &ym1i, 32);
+      }
+    });
     hipLaunchKernelGGL(k_vprep0_split, dim3((d.B + 63) / 64), dim3(64), 0, vb->stream, d, chal, vb->hinv, vb->cst, vb->zpow);
     hipLaunchKernelGGL(k_vprep0_pow, VB_GRID((size_t)d.nm * B), d, vb->cst, vb->ypowinv);
     hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
@@ -1098,12 +1118,14 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
   // them across the workgroup (batchinv.h) lengthens it (1.58 -> 1.71 ms).  BP_ROUND_BATCHINV=1 selects the shared form.
   static const bool round_batch = getenv("BP_ROUND_BATCHINV") && atoi(getenv("BP_ROUND_BATCHINV")) != 0;
   if (vb->split) {
-    for (size_t p = 0; p < B; p++) {  // x_r^-1 on the host (`x` is host memory in both modes)
-      u256 xv;
-      memcpy(&xv, x + p * 32, 32);
-      xv = host::fr_inv_mont_host(Fr::to_mont(Fr::reduce_once(xv)));
-      memcpy(vb->hinv + ((size_t)HI_XINV * B + p) * 32, &xv, 32);
-    }
+    vbatch_host_for(vb, B, [&](size_t p0, size_t p1) {  // x_r^-1 on the host (`x` is host memory in both modes)
+      for (size_t p = p0; p < p1; p++) {
+        u256 xv;
+        memcpy(&xv, x + p * 32, 32);
+        xv = host::fr_inv_mont_host(Fr::to_mont(Fr::reduce_once(xv)));
+        memcpy(vb->hinv + ((size_t)HI_XINV * B + p) * 32, &xv, 32);
+      }
+    });
     hipLaunchKernelGGL(k_round_bits, dim3(d.B), dim3(256), 0, vb->stream, d, round, xin, vb->hinv, vb->xk_m, vb->xkinv_m,
                        vb->sh, vb->acc_x, vb->hx);
     BP_TRY(hipGetLastError());
@@ -1177,10 +1199,12 @@ int vbatch_join_side(bp_vbatch* vb) {
 
 int vbatch_collect(bp_vbatch* vb, uint8_t* out_commitment) {
   if (!vb->split || !vb->collect_pending) return BP_OK;
-  for (size_t p = 0; p < vb->d.B; p++) {
-    affine a = host::xyzz_to_affine_host(vb->hx[p]);
-    memcpy(out_commitment + p * 64, &a, 64);
-  }
+  vbatch_host_for(vb, vb->d.B, [&](size_t p0, size_t p1) {
+    for (size_t p = p0; p < p1; p++) {
+      affine a = host::xyzz_to_affine_host(vb->hx[p]);
+      memcpy(out_commitment + p * 64, &a, 64);
+    }
+  });
   vb->collect_pending = false;
   return BP_OK;
 }
@@ -1211,9 +1235,18 @@ int vbatch_wait(bp_vbatch* vb) {
 extern "C" {
 
 int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, bp_vbatch** out) {
+  return vbatch_create_ex(ctx, n_bits, m, batch, false, out);
+}
+
+}  // extern "C"
+
+// pooled_host: the caller (bp_vjob) lends its hashing threads to the latency path's host loops (bp_vbatch::pfor), which
+// moves the size at which that path stops paying from ~100 to ~1,000 proofs
+int bp::vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, bool pooled_host, bp_vbatch** out) {
   if (!ctx) return BP_ERR_ARG;
   BP_REQUIRE(out, "null pointer");
   *out = nullptr;
+  const uint32_t split_max = pooled_host ? vsplit_max_b() : (vsplit_max_b() < VSPLIT_SERIAL_MAX_B ? vsplit_max_b() : VSPLIT_SERIAL_MAX_B);
   BP_REQUIRE(n_bits >= 1 && n_bits <= 128 && (n_bits & (n_bits - 1)) == 0, "n_bits must be a power of two <= 128");
   BP_REQUIRE(m >= 1 && (m & (m - 1)) == 0, "m must be a power of two (pad commitments with O, Verifier.hs:37-38)");
   BP_REQUIRE(batch >= 1 && batch <= (1u << 22), "batch must be in 1..2^22");
@@ -1271,7 +1304,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
     vb->rpre = c.take<u256>((size_t)11 * (d.k ? d.k : 1) * B);
     vb->rtab = c.take<uint8_t>((size_t)15 * (d.k ? d.k : 1) * B * 64);
     {
-      const size_t sb = B <= VSPLIT_MAX_B ? B : 1;
+      const size_t sb = B <= split_max ? B : 1;
       vb->sh = c.take<xyzz>((size_t)(vb->npts - VP_S) * sb * GLV_LANE_BITS);  // bit tables of rows S.. (16 KB a point)
       vb->acc_x = c.take<xyzz>(sb);
       vb->fpart = c.take<xyzz>(sb * 64);
@@ -1284,7 +1317,7 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   vb->t_pending = false;
   vb->tab_pending = false;
   vb->begun_complete = false;
-  vb->split = batch <= VSPLIT_MAX_B && d.k > 0 && !(getenv("BP_NO_SPLIT") && atoi(getenv("BP_NO_SPLIT")) != 0);
+  vb->split = batch <= split_max && d.k > 0 && !(getenv("BP_NO_SPLIT") && atoi(getenv("BP_NO_SPLIT")) != 0);
   hipError_t e = hipSuccess;
   vb->done = nullptr;
   e = hipEventCreateWithFlags(&vb->done, hipEventDisableTiming);
@@ -1343,6 +1376,8 @@ int bp_vbatch_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, b
   *out = vb;
   return BP_OK;
 }
+
+extern "C" {
 
 void bp_vbatch_destroy(bp_vbatch* vb) {
   if (!vb) return;

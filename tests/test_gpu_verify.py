@@ -135,11 +135,11 @@ def degenerate_lr(pr, kind, r):
     return dict(pr, productProof=ipp)
 
 
-@pytest.mark.parametrize("copies", [1, 500])
+@pytest.mark.parametrize("copies", [1, 50, 500])
 def test_round_kernels_special_cases(eng_gens, copies):
-    """The one-lane-per-proof path is only taken by batches of more than 16 proofs (two lanes per proof up to 8,192
-    proofs, one lane above): every round's accumulator against the oracle for honest proofs and for proofs whose
-    L_r / R_r are O, equal or opposite (the exceptional cases of the mixed addition inside the chains)."""
+    """Three forms of the rounds: one lane per scalar bit up to 768 proofs (17 here), two lanes per proof up to 8,192
+    (850), one lane per proof above (8,500).  Every round's accumulator against the oracle for honest proofs and for
+    proofs whose L_r / R_r are O, equal or opposite (the exceptional cases of the additions inside the chains)."""
     n, rng = 8, random.Random(77)
     base = []
     for _ in range(2):
