@@ -615,6 +615,103 @@ k_round_pair(VDims d, uint32_t round, const uint8_t* __restrict__ xk /*[B][32] c
   }
 }
 
+// The stage-1 tail in the same form: P = acc1 + x*S + A with the chain of x*S on a pair of lanes.  x = m1 + m2 lambda with
+// non-negative halves (glv_split_pos), so the chain adds the AFFINE points S and phi(S) (both free) by mixed additions -
+// one per set bit, 1.0 per step on average - instead of full additions of an XYZZ table entry.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_stage1_tail_pair(VDims d, const uint8_t* __restrict__ pts, const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
+                   uint8_t* __restrict__ sphi /*[B][2][64]: S, phi(S)*/, uint8_t* __restrict__ acc_aff,
+                   uint8_t* __restrict__ host_out, uint8_t* __restrict__ host_txt) {
+  __shared__ uint32_t lds[256 * 2 * DEC_REC_WORDS];
+  __shared__ uint32_t xch[RP_PROOFS * 36];
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t tid = threadIdx.x, first = blockIdx.x * RP_PROOFS;
+  const uint32_t p = first + tid;
+  const bool solo = tid < RP_PROOFS, live = solo && p < d.B;
+  const size_t B = d.B;
+  if (solo) {  // whole waves
+    GlvPos s0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) s0.m1[i] = s0.m2[i] = 0;
+    if (live) {
+      s0 = glv_split_pos(Fr::from_mont(ldm(cst, C_X * B + p)));
+      const affine S = ld_affine(pts + ((size_t)VP_S * B + p) * 64);
+      st_affine(sphi + (size_t)p * 128, S);
+      st_affine(sphi + (size_t)p * 128 + 64, glv_phi(S));
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      xch[tid * 36 + i] = s0.m1[i];
+      xch[tid * 36 + 5 + i] = s0.m2[i];
+    }
+  }
+  __syncthreads();  // also orders the workgroup's stores to sphi before its loads below
+  {
+    const uint32_t q = tid >> 1, pq = first + q;
+    const bool odd = (tid & 1u) != 0;
+    uint32_t m[2][5];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int i = 0; i < 5; i++) m[h][i] = xch[q * 36 + h * 5 + i];
+    __syncthreads();
+    pair29 acc;
+    acc.c0 = fe29_zero();
+    acc.c1 = fe29_zero();
+    if (pq < d.B) {
+      BitReg b0 = bitreg_init5(m[0]), b1 = bitreg_init5(m[1]);
+      const uint8_t* E = sphi + (size_t)pq * 128;
+#pragma unroll 1
+      for (int i = 0; i < GLV_BITS; i++) {
+        const uint32_t idx = bitreg_next(b0) | (bitreg_next(b1) << 1);
+        acc = pair_dbl(acc, odd);
+#pragma unroll 1
+        for (uint32_t t = 0; t < 2; t++)  // ONE addition site
+          if ((idx >> t) & 1u) acc = pair_madd(acc, E + t * 64, odd);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      xch[q * 36 + (odd ? 0 : 9) + i] = acc.c0.v[i];
+      xch[q * 36 + (odd ? 18 : 27) + i] = acc.c1.v[i];
+    }
+  }
+  __syncthreads();
+  affine out = affine_inf();
+  if (live) {
+    xyzz29 a29;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      a29.X.v[i] = xch[tid * 36 + i];
+      a29.Y.v[i] = xch[tid * 36 + 9 + i];
+      a29.ZZ.v[i] = xch[tid * 36 + 18 + i];
+      a29.ZZZ.v[i] = xch[tid * 36 + 27 + i];
+    }
+    xyzz acc = xyzz_add(xyzz29_to(a29), ld_xyzz(&acc1[p]));
+    acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
+    out = xyzz_to_affine_with_inv(acc, fq_inv29(acc.ZZZ));
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  }
+  if (host_txt) {
+    uint32_t w[2 * DEC_REC_WORDS];
+#pragma unroll
+    for (int j = 0; j < 2 * DEC_REC_WORDS; j++) w[j] = 0;
+    if (solo) {
+      uint32_t wx[DEC_REC_WORDS], wy[DEC_REC_WORDS];
+      u256_to_dec_record(out.x, wx);
+      u256_to_dec_record(out.y, wy);
+#pragma unroll
+      for (int j = 0; j < DEC_REC_WORDS; j++) {
+        w[j] = wx[j];
+        w[DEC_REC_WORDS + j] = wy[j];
+      }
+    }
+    const uint32_t valid = d.B - first < RP_PROOFS ? d.B - first : RP_PROOFS;
+    block_store_records<2 * DEC_REC_WORDS>(lds, w, host_txt + (size_t)first * 2 * DEC_REC, valid);
+  }
+}
+
 // ---- small batches: the latency path ------------------------------------------------------------------------
 // With a handful of proofs the 129-step chains of k_round / k_stage1_tail / k_var_terms leave the GPU idle and set
 // the latency of a verification.  Every point of a proof (S, T1, T2, L_r, R_r, V_j) is known before any challenge:
@@ -1080,8 +1177,14 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   // A device-to-host copy command after the kernel would serialise the chunks' streams against each
   // other (measured: benchmarks/concurrency_test3.hip); with pinned outputs the kernel stores its
   // result to host memory itself.
-  hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
-                     vb->direct_host ? out_text : nullptr);
+  // chunks of at most 8,192 proofs: the chain of x*S on pairs of lanes, as in the rounds (BP_ROUND_PAIR)
+  static const int pair_env = getenv("BP_ROUND_PAIR") ? atoi(getenv("BP_ROUND_PAIR")) : -1;
+  if (pair_env < 0 ? B <= 8192 : pair_env != 0)
+    hipLaunchKernelGGL(k_stage1_tail_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, vb->stream, d, vb->pts,
+                       vb->cst, vb->acc1, (uint8_t*)vb->vtab, vb->acc_aff, direct, vb->direct_host ? out_text : nullptr);
+  else
+    hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
+                       vb->direct_host ? out_text : nullptr);
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
