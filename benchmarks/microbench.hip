@@ -1,10 +1,12 @@
 // gfx950 integer-VALU microbenchmarks: measures the roofline denominator
 // (v_mad_u64_u32 issue rate) and the field / point primitive throughput.
 // Build: hipcc -O3 --offload-arch=gfx950 -o microbench microbench.hip
+#include <string.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include "../bulletproofs_amd/csrc/lanes29.h"
 #include "../bulletproofs_amd/csrc/ec.h"
 #include "../bulletproofs_amd/csrc/fq29.h"
 using namespace bp;
@@ -197,6 +199,45 @@ __global__ void __launch_bounds__(256) k_point29_aff(uint32_t* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// ---- one point operation over a quad / a pair of lanes (lanes29.h), and the one-lane 29-bit forms beside them ----
+// op 0: xyzz29_dbl  1: xyzz29_add  2: quad_dbl  3: quad_add  4: pair_dbl  5: pair_dbl + pair_madd  6: xyzz29_dbl + xyzz29_madd
+// Every group of lanes (1, 4 or 2) works on its own point; the result is the affine x, y of lane group's point.
+template <int OP>
+__global__ void __launch_bounds__(256) k_lanes(uint32_t* out, uint8_t* scratch, int iters) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int G = (OP == 2 || OP == 3) ? 4 : ((OP == 4 || OP == 5) ? 2 : 1);
+  const uint32_t grp = t / G, lane = t % G;
+  affine g = affine_gen();
+  u256 k = seed_fe(grp + 1);
+  k.v[7] = 0; k.v[6] = 0; k.v[5] = 0; k.v[4] = 0; k.v[3] = 0; k.v[2] = 0; k.v[1] = 0; k.v[0] = (k.v[0] & 0xffff) + 2;
+  const xyzz start = xyzz_mul_affine(g, k);
+  const xyzz29 q29 = xyzz29_from(xyzz_dbl(xyzz_dbl(start)));
+  st_affine(scratch + (size_t)t * 64, g);  // the mixed additions read their point from memory, like the kernels
+  xyzz29 acc = xyzz29_from(start);
+  if (OP == 0) for (int it = 0; it < iters; it++) acc = xyzz29_dbl(acc);
+  if (OP == 1) for (int it = 0; it < iters; it++) acc = xyzz29_add(acc, q29);
+  if (OP == 6) for (int it = 0; it < iters; it++) acc = xyzz29_madd(xyzz29_dbl(acc), ld_affine(scratch + (size_t)t * 64), false);
+  if (OP == 2 || OP == 3) {
+    fe29 P = quad_spread(acc, lane);
+    const fe29 Q = quad_spread(q29, lane);
+    for (int it = 0; it < iters; it++) P = OP == 2 ? quad_dbl(P, lane) : quad_add(P, Q, lane);
+    acc = quad_gather(P);
+  }
+  if (OP == 4 || OP == 5) {
+    const bool odd = lane != 0;
+    pair29 P = pair_spread(acc, odd);
+    for (int it = 0; it < iters; it++) {
+      P = pair_dbl(P, odd);
+      if (OP == 5) P = pair_madd(P, scratch + (size_t)t * 64, odd);
+    }
+    acc = pair_gather(P, odd);
+  }
+  affine a = xyzz_to_affine(xyzz29_to(acc));
+  uint32_t s = 0;
+  for (int i = 0; i < 8; i++) s ^= a.x.v[i] ^ (a.y.v[i] * 3u);
+  out[t] = s;
+}
+
 template <class F>
 static double time_ms(F launch, int reps = 3) {
   hipEvent_t e0, e1;
@@ -218,6 +259,43 @@ int main(int argc, char** argv) {
   printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d}\n", prop.name, cus, prop.clockRate / 1000);
   void* buf; CK(hipMalloc(&buf, 64u << 20));
   const int threads = 256;
+  if (argc > 1 && !strcmp(argv[1], "--lanes")) {
+    // latency of ONE dependent point operation at one wave per SIMD (and two), one lane against a quad / a pair
+    uint8_t* scr; CK(hipMalloc(&scr, (size_t)cus * 8 * 256 * 64));
+    for (int wps = 1; wps <= 2; wps *= 2) {
+      int blocks = cus * wps;
+      const int iters = 300;
+#define LN(name, OP) { double ms = time_ms([&] { hipLaunchKernelGGL((k_lanes<OP>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, scr, iters); }); \
+      printf("{\"bench\": \"%s\", \"waves_per_simd\": %d, \"us_per_op\": %.2f}\n", name, wps, ms * 1e3 / iters); }
+      LN("xyzz29_dbl (one lane)", 0) LN("quad_dbl", 2) LN("pair_dbl", 4) LN("xyzz29_add (one lane)", 1) LN("quad_add", 3)
+      LN("xyzz29_dbl + xyzz29_madd (one lane)", 6) LN("pair_dbl + pair_madd", 5)
+#undef LN
+    }
+    // parity: the same chains end at the same affine points (compared group by group)
+    const int blocks = 4, iters = 23;
+    uint32_t* o[7];
+    std::vector<uint32_t> h[7];
+    for (int i = 0; i < 7; i++) { CK(hipMalloc(&o[i], blocks * 256 * 4)); h[i].resize(blocks * 256); }
+    hipLaunchKernelGGL((k_lanes<0>), dim3(blocks), dim3(256), 0, 0, o[0], scr, iters);
+    hipLaunchKernelGGL((k_lanes<1>), dim3(blocks), dim3(256), 0, 0, o[1], scr, iters);
+    hipLaunchKernelGGL((k_lanes<2>), dim3(blocks), dim3(256), 0, 0, o[2], scr, iters);
+    hipLaunchKernelGGL((k_lanes<3>), dim3(blocks), dim3(256), 0, 0, o[3], scr, iters);
+    hipLaunchKernelGGL((k_lanes<4>), dim3(blocks), dim3(256), 0, 0, o[4], scr, iters);
+    hipLaunchKernelGGL((k_lanes<5>), dim3(blocks), dim3(256), 0, 0, o[5], scr, iters);
+    hipLaunchKernelGGL((k_lanes<6>), dim3(blocks), dim3(256), 0, 0, o[6], scr, iters);
+    for (int i = 0; i < 7; i++) CK(hipMemcpy(h[i].data(), o[i], h[i].size() * 4, hipMemcpyDeviceToHost));
+    auto cmp = [&](const char* name, int one, int many, int G) {
+      size_t bad = 0, n = h[many].size() / G;
+      for (size_t g2 = 0; g2 < n; g2++)
+        for (int l = 0; l < G; l++) bad += h[many][g2 * G + l] != h[one][g2];
+      printf("{\"check\": \"%s\", \"groups\": %zu, \"mismatches\": %zu}\n", name, n, bad);
+    };
+    cmp("quad_dbl chain == xyzz29_dbl chain", 0, 2, 4);
+    cmp("quad_add chain == xyzz29_add chain", 1, 3, 4);
+    cmp("pair_dbl chain == xyzz29_dbl chain", 0, 4, 2);
+    cmp("pair_dbl + pair_madd chain == xyzz29_dbl + xyzz29_madd chain", 6, 5, 2);
+    return 0;
+  }
   for (int wps = 1; wps <= 8; wps *= 2) {  // waves per SIMD
     int blocks = cus * wps;                // 256 threads = 4 waves = 1 wave/SIMD per block
     const int iters = 4000;

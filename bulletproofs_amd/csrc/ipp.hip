@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) k_lincomb2_add(const uint8_t* __restrict__
 // side), and a product k * p is then one lane per bit (glv.h glv_bit_lane: at most one addition) and a
 // workgroup sum.  Exact: the lanes' terms add up to the same group element.
 // The chain of 127 doublings is what a single proof's verifier waits for first (x * S needs S's table), so a point is
-// spread over a quad of lanes (lanes29.h: a doubling in three rounds of products, 2.1 us against 3.9 us); every lane
+// spread over a quad of lanes (lanes29.h: a doubling in three rounds of products, 2.7 us against 4.2 us); every lane
 // stores its own coordinate of each multiple.
 __global__ void __launch_bounds__(64) k_bit_tables(const uint8_t* __restrict__ pts, uint32_t n, xyzz* __restrict__ sh /*[n][128]*/) {
   const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, lane = threadIdx.x & 3u;

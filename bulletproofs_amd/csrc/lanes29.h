@@ -7,10 +7,10 @@
 // quad, no LDS).  All lanes run ONE instruction stream; a lane without a useful product in some round multiplies whatever
 // it holds.  Arithmetic, limb classes and the exceptional-case filter are those of fq29.h (xyzz29_dbl, xyzz29_madd).
 //
-//   quad  (4 lanes): doubling in 3 rounds instead of 9 products (2.1 us against 3.5-3.9 us in one lane), full addition in
-//         4 rounds instead of 14 (4.3 us against 6.4 us).  msm.hip k_final / k_window_sum_quad, ipp.hip k_bit_tables, and
+//   quad  (4 lanes): doubling in 3 rounds instead of 9 products (2.7 us against 4.2 us in one lane), full addition in
+//         4 rounds instead of 14 (3.1 us against 5.7 us; benchmarks/microbench --lanes, one wave per SIMD).  msm.hip k_final / k_window_sum_quad, ipp.hip k_bit_tables, and
 //         block_sum_quad: the workgroup sums of the one-lane-per-bit products and of the provers' fixed-base terms.
-//   pair  (2 lanes): doubling + mixed addition in 5 + 5 rounds instead of 9 + 10, for only ~1/3 more instructions in
+//   pair  (2 lanes): doubling + mixed addition in 5 + 5 rounds instead of 9 + 10, (5.2 us against 6.8 us) for only ~1/3 more instructions in
 //         total (the quad form would be 3 + 4 rounds for more than twice the instructions).  verify.hip k_round_pair,
 //         k_stage1_tail_pair.
 // Every caller keeps whole quads / pairs active together: the permutes only read lanes of the same group.
@@ -140,7 +140,7 @@ __device__ __forceinline__ fe29 quad_add_total(const fe29& pc, const fe29& qc, u
 }
 // Sum of one XYZZ term per thread over a workgroup of 64, 128 or 256 threads (thread 0 returns it), by quads: the terms
 // cross LDS coordinate by coordinate, quad q adds the terms q, q + n/4, q + n/2, q + 3n/4, then a tree over the n/4 quads.
-// 3 + log2(n/4) additions of 4.3 us deep, against log2(n) levels of ~12 us for shuffled single-lane additions.
+// 3 + log2(n/4) additions of 3-4 us deep, against log2(n) levels of ~12 us for shuffled single-lane additions.
 // lds: n * 36 words.
 __device__ __forceinline__ xyzz block_sum_quad(const xyzz& term, uint32_t* lds) {
   const uint32_t t = threadIdx.x, n = blockDim.x, nq = n >> 2, q = t >> 2, lane = t & 3u;
