@@ -628,8 +628,8 @@ __global__ void __launch_bounds__(256) k_window_sum(const xyzz* __restrict__ seg
 }
 
 // ---- 7q. window sums with every point spread over a quad of lanes (lanes29.h) -----------------------------------------
-// A quad does an addition in 4 rounds of products instead of 14, on the 29-bit limbs (3.1 us against 5.7 us on 29-bit limbs in one lane, 6.4 us on 8 x 32, at one wave
-// per SIMD); each lane loads and stores only its own coordinate.  (The segment step in the same form was measured too:
+// A quad does an addition in 4 rounds of products instead of 14, on the 29-bit limbs (3.1 us, against 5.7 us in one lane
+// on those limbs and 6.4 us on 8 x 32, at one wave per SIMD); each lane loads and stores only its own coordinate.  (The segment step in the same form was measured too:
 // four times the lanes put two waves on every SIMD and the kernel took the same 0.23 ms, so it stays one lane per
 // segment.)
 // out[w][g] = sum of slice g of in[w][0..n): one workgroup of 256 lanes (64 quads, one wave per SIMD: two waves on a SIMD
