@@ -29,6 +29,9 @@ class BpError(RuntimeError):
     pass
 
 
+ERR_REFERENCE_FAILS = -8  # BP_ERR_REFERENCE_FAILS
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/bpgpu.h declares
@@ -83,6 +86,7 @@ SYMBOLS = {
     "bp_log_base2": (_int, [_u8p, _sz]),
     "bp_transcript": (_int, [_int, _int, _u8p, _u8p, _u8p, _sz, _u8p]),
     "bp_rangeproof_verify_batch": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _u8p, _u8p, _u8p]),
+    "bp_rangeproof_verify": (_int, [_vp, _u8p, _sz, _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint32, _u8p]),
     "bp_vjob_create": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _int,
                               ctypes.POINTER(_vp)]),
     "bp_vjob_destroy": (None, [_vp]),
@@ -199,7 +203,9 @@ class Engine:
 
     def _check(self, rc, what):
         if rc != 0:
-            raise BpError("%s failed (%d): %s" % (what, rc, self.lib.bp_last_error(self.h).decode()))
+            e = BpError("%s failed (%d): %s" % (what, rc, self.lib.bp_last_error(self.h).decode()))
+            e.code = rc
+            raise e
 
     def profile(self, enable=True):
         self._check(self.lib.bp_ctx_profile(self.h, 1 if enable else 0), "bp_ctx_profile")
@@ -368,6 +374,22 @@ class Engine:
         self._check(self.lib.bp_rangeproof_verify_batch(self.h, n_bits, m, batch, scalars, points, out),
                     "bp_rangeproof_verify_batch")
         return [b != 0 for b in out.raw]
+
+    def verify_proof(self, upper_bound, v_commits, proof):
+        """MultiRangeProof.verifyProof upperBound vCommits proof (MultiRangeProof/Verifier.hs:19-39) for one proof,
+        total like the reference: any bound, any number of L/R pairs.  Raises BpError with .code =
+        ERR_REFERENCE_FAILS where the reference raises."""
+        nbytes = max(1, (upper_bound.bit_length() + 7) // 8)
+        ipp = proof["productProof"]
+        k = min(len(ipp["lCommits"]), len(ipp["rCommits"]))  # zip
+        sc = enc_scalars([proof["tBlinding"], proof["mu"], proof["t"], ipp["l"], ipp["r"]])
+        pts = enc_points([proof["aCommit"], proof["sCommit"], proof["t1Commit"], proof["t2Commit"]]
+                         + list(ipp["lCommits"])[:k] + list(ipp["rCommits"])[:k])
+        out = ctypes.create_string_buffer(1)
+        self._check(self.lib.bp_rangeproof_verify(self.h, upper_bound.to_bytes(nbytes, "little"), nbytes,
+                                                  enc_points(v_commits), len(v_commits), sc, pts, k, out),
+                    "bp_rangeproof_verify")
+        return out.raw[0] != 0
 
     def ipp_prove(self, gs, hs, u, P, ls, rs):
         """IPP.generateProof (InnerProductProof/Prover.hs:17-26) -> dict(lCommits, rCommits, l, r)."""

@@ -13,6 +13,7 @@
 #include "fixedbase.h"
 #include "glv.h"
 #include "host_inv.h"
+#include "validate.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -523,6 +524,15 @@ int bp_ac_verify(bp_ctx* ctx, uint32_t n, uint32_t q, uint32_t m, const uint8_t*
   BP_REQUIRE(proof_scalars && proof_points && verdict, "null pointer");
   BP_REQUIRE(q == 0 || ((n == 0 || (wL && wR && wO)) && cs), "null pointer");
   BP_REQUIRE(m == 0 || (v_commits && (q == 0 || wV)), "null pointer");
+  // untrusted encodings the reference's types cannot hold do not verify (validate.h; as in the batch range verifier)
+  {
+    bool ok = points_encoding_valid(proof_points, 10 + (size_t)2 * k) && points_encoding_valid(v_commits, m);
+    for (int i = 0; i < 5; i++) ok = ok && scalar_encoding_valid(proof_scalars + 32 * i);
+    if (!ok) {
+      *verdict = 0;
+      return BP_OK;
+    }
+  }
   BP_TRY(hipSetDevice(ctx->device));
   const ShowStyle style = (ShowStyle)ctx->show_style;
   ProverWs w;

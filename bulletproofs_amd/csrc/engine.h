@@ -106,6 +106,9 @@ struct bp_ctx {
   } while (0)
 
 namespace bp {
+// ops.hip: *d_bad (one u32, device) = 1 iff some of the n device-resident points is neither O nor a canonically
+// encoded point of the curve; asynchronous on ctx->stream
+int points_invalid_dev(bp_ctx* ctx, const uint8_t* d_points, size_t n, uint32_t* d_bad);
 // msm.hip
 // A stream for one chunk of a batch job, from the context's concurrent set (round-robin).  Not owned by the caller.
 hipStream_t ctx_chunk_stream(bp_ctx* ctx);

@@ -66,7 +66,20 @@ __global__ void __launch_bounds__(256) k_on_curve(const uint8_t* __restrict__ po
                                                  uint8_t* __restrict__ ok) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  ok[i] = affine_on_curve(ld_affine(points + (size_t)i * 64)) ? 1 : 0;
+  // O, or canonical coordinates (x, y < p: an `Fq` is always reduced) that satisfy the curve equation
+  const affine a = ld_affine(points + (size_t)i * 64);
+  const u256 q = fq_p();
+  ok[i] = (affine_is_inf(a) || (!u256_geq(a.x, q) && !u256_geq(a.y, q) && affine_on_curve(a))) ? 1 : 0;
+}
+
+// *bad |= 1 when some point is neither O nor a canonically encoded point of the curve (the caller clears *bad)
+__global__ void __launch_bounds__(256) k_points_invalid(const uint8_t* __restrict__ points, uint32_t n,
+                                                       uint32_t* __restrict__ bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const affine a = ld_affine(points + (size_t)i * 64);
+  const u256 q = fq_p();
+  if (!(affine_is_inf(a) || (!u256_geq(a.x, q) && !u256_geq(a.y, q) && affine_on_curve(a)))) atomicOr(bad, 1u);
 }
 
 template <class F>
@@ -145,6 +158,18 @@ static int with_staging(bp_ctx* ctx, std::initializer_list<std::pair<const void*
 
 #define BP_CHECK_N(n) BP_REQUIRE((n) < (1ull << 31), "n must be below 2^31")
 #define GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, ctx->stream
+
+namespace bp {
+// device pointers, asynchronous on ctx->stream: *d_bad (one u32) = 1 iff some of the n points has an invalid encoding
+int points_invalid_dev(bp_ctx* ctx, const uint8_t* d_points, size_t n, uint32_t* d_bad) {
+  BP_TRY(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
+  if (n == 0) return BP_OK;
+  BP_CHECK_N(n);
+  hipLaunchKernelGGL(k_points_invalid, GRID(n), d_points, (uint32_t)n, d_bad);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+}  // namespace bp
 
 extern "C" {
 

@@ -12,6 +12,7 @@
 #include "fixedbase.h"
 #include "glv.h"
 #include "host_inv.h"
+#include "validate.h"
 
 using namespace bp;
 using namespace bp::host;
@@ -788,7 +789,9 @@ int bp_ipp_prove(bp_ctx* ctx, uint32_t n, const uint8_t* Gs, const uint8_t* Hs, 
 // scalars of cProof = l <s, Gs> + r <reverse s, Hs> + (l r) bH are a kernel when n is a power of two that the bases
 // cover (frvec.hip), else the reference's Map walk on the host (first insert wins; `sumExps` truncates to the shorter
 // list, Utils.hs:79); one variable-base MSM of 2n + 1 terms; verdict = (acc == cProof) on affine bytes.
-// Where the reference would fail with an index error (fewer rounds than logBase2 n), this returns BP_ERR_ARG.
+// Where the reference would fail with an index error (fewer rounds than logBase2 n), this returns
+// BP_ERR_REFERENCE_FAILS.  Encodings the reference's types cannot hold (a point that is neither O nor on the curve, a
+// coordinate >= p, l or r >= r) do not verify (validate.h), as in the batch verifier.
 int bp_ipp_verify(bp_ctx* ctx, uint64_t n64, const uint8_t* Gs, uint32_t n_gs, const uint8_t* Hs, uint32_t n_hs,
                   const uint8_t* u, const uint8_t* P, const uint8_t* L, const uint8_t* R, uint32_t k, const uint8_t* l,
                   const uint8_t* r, uint8_t* verdict) {
@@ -801,9 +804,14 @@ int bp_ipp_verify(bp_ctx* ctx, uint64_t n64, const uint8_t* Gs, uint32_t n_gs, c
   // logBase2 n = floor (logBase 2.0 n) (Utils.hs:93-94); for n = 0 the reference's range [0 .. logBase2 n - 1] is empty
   uint32_t lg = 0;
   while (n >= 2 && (2u << lg) <= n) lg++;
+  if (!point_encoding_valid(u) || !point_encoding_valid(P) || !points_encoding_valid(L, k) ||
+      !points_encoding_valid(R, k) || !scalar_encoding_valid(l) || !scalar_encoding_valid(r)) {
+    *verdict = 0;
+    return BP_OK;
+  }
   if (n >= 2 && lg > k) {
     ctx->err = "bp_ipp_verify: fewer L/R rounds than logBase2 n (the reference fails with an index error here)";
-    return BP_ERR_ARG;
+    return BP_ERR_REFERENCE_FAILS;
   }
   BP_TRY(hipSetDevice(ctx->device));
   const ShowStyle style = (ShowStyle)ctx->show_style;
@@ -847,7 +855,7 @@ int bp_ipp_verify(bp_ctx* ctx, uint64_t n64, const uint8_t* Gs, uint32_t n_gs, c
         if (i1 >= n || present[i1]) continue;
         if (!present[i]) {
           ctx->err = "bp_ipp_verify: mkOtherExponents reads a missing key (the reference fails here)";
-          return BP_ERR_ARG;
+          return BP_ERR_REFERENCE_FAILS;
         }
         accm[i1] = fr_mul(accm[i], fr_sqr(chal[k - 1 - j]));
         present[i1] = 1;
@@ -868,12 +876,16 @@ int bp_ipp_verify(bp_ctx* ctx, uint64_t n64, const uint8_t* Gs, uint32_t n_gs, c
   if (a) BP_TRY(hipMemcpyAsync(w.pts, Gs, a * 64, hipMemcpyHostToDevice, st));
   if (b) BP_TRY(hipMemcpyAsync(w.pts + a * 64, Hs, b * 64, hipMemcpyHostToDevice, st));
   BP_TRY(hipMemcpyAsync(w.pts + (a + b) * 64, u, 64, hipMemcpyHostToDevice, st));
+  uint32_t* d_bad = (uint32_t*)(w.small + 11 * 64);  // the bases are untrusted too: checked where they landed
+  if ((rc = points_invalid_dev(ctx, w.pts, a + b, d_bad)) != BP_OK) return rc;
   uint8_t* d_out = w.small + 15 * 64;
   if ((rc = msm_run(ctx, w.sc, w.pts, a + b + 1, 0, d_out, nullptr)) != BP_OK) return rc;
   uint8_t cproof[64];
+  uint32_t bad = 0;
   BP_TRY(hipMemcpyAsync(cproof, d_out, 64, hipMemcpyDeviceToHost, st));
+  BP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
   BP_TRY(hipStreamSynchronize(st));
-  *verdict = memcmp(cproof, acc, 64) == 0 ? 1 : 0;  // c == cProof   (:27)
+  *verdict = (!bad && memcmp(cproof, acc, 64) == 0) ? 1 : 0;  // c == cProof   (:27)
   return BP_OK;
 }
 

@@ -42,6 +42,9 @@ extern "C" {
 #define BP_ERR_NOT_IN_RANGE (-5)    /* RangeProofError ValuesNotInRange  (RangeProof/Internal.hs:40-45) */
 #define BP_ERR_BOUND_TOO_LARGE (-6) /* RangeProofError UpperBoundTooLarge */
 #define BP_ERR_N_NOT_POW2 (-7)      /* RangeProofError NNotPowerOf2 */
+#define BP_ERR_REFERENCE_FAILS (-8) /* the reference's own evaluation raises on these arguments (`challenges !! j` with
+                                       too few L/R pairs, `2 ^ (-1)` for an empty commitment list, `recip 0`): the
+                                       shim raises the same way; no Bool exists to return */
 
 typedef struct bp_ctx bp_ctx;
 
@@ -85,7 +88,7 @@ int bp_ctx_profile_read(bp_ctx* ctx, int kernel, double* total_ms, uint64_t* lau
  * bp_add_two_mul    out[i] = e0[i]*p0[i] + e1[i]*p1[i]
  *                   replaces `addTwoMulP` (Utils.hs:72-73), incl. the generator
  *                   folds of InnerProductProof/Prover.hs:81-82.
- * bp_point_on_curve ok[i] = 1 if points[i] satisfies y^2 = x^3 + 7 or is O
+ * bp_point_on_curve ok[i] = 1 if points[i] is O or has canonical coordinates (< p) that satisfy y^2 = x^3 + 7
  *                   replaces `def` (Utils.hs:42).
  */
 int bp_point_mul(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
@@ -238,6 +241,25 @@ int bp_transcript(int style, int which, const uint8_t* pts, const uint8_t* scs, 
                   uint8_t* out);
 int bp_rangeproof_verify_batch(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, const uint8_t* scalars,
                                const uint8_t* points, uint8_t* verdicts);
+/* bp_rangeproof_verify   *verdict = MultiRangeProof.verifyProof upperBound vCommits proof for ONE proof
+ *                   (MultiRangeProof/Verifier.hs:19-88), TOTAL over its arguments like the reference's function, which
+ *                   checks neither the bound nor the proof's shape: n = logBase2 upperBound in Double arithmetic
+ *                   (Utils.hs:93-94; any integer, e.g. upperBound = 12 gives n = 3, upperBound = 0 acts as n = 0),
+ *                   m = length vCommits (unpadded; the padding with O to 2^log2Ceil m happens inside, Verifier.hs:37-38),
+ *                   k = the number of (L, R) pairs `zip lCommits rCommits` yields - whatever the proof holds.
+ *                   upper_bound: little-endian integer of ub_len bytes.  proof_scalars: 5 x 32 B (tBlinding, mu, t,
+ *                   l, r); proof_points: (4 + 2k) x 64 B (aCommit, sCommit, t1Commit, t2Commit, L_0.., R_0..).
+ *                   A proof of the honest shape (n a power of two <= 128, k = log2(n m)) runs on the batch engine;
+ *                   every other input follows the reference's definitions literally on the same GPU primitives
+ *                   (computeLRCommitment over materialised hs', RangeProof/Internal.hs:169-206; mkChallenges over k
+ *                   pairs and mkOtherExponents for any n, InnerProductProof/Verifier.hs:40-73).  This is the domain
+ *                   of the reference's negative test prop_differentUpperBound (test/Test/Protocol/RangeProof.hs:173-181).
+ *                   Returns BP_ERR_REFERENCE_FAILS where the reference raises instead of returning a Bool: m = 0, or
+ *                   verifyTPoly holds and the proof has fewer pairs than logBase2 (n m) (`and` is lazy: a failing
+ *                   verifyTPoly gives False first).  BP_ERR_STATE when n * 2^log2Ceil m exceeds the context's
+ *                   generators (`gs`, `hs` are infinite lists in the reference; derive more and call again). */
+int bp_rangeproof_verify(bp_ctx* ctx, const uint8_t* upper_bound, size_t ub_len, const uint8_t* v_commits, uint32_t m,
+                         const uint8_t* proof_scalars, const uint8_t* proof_points, uint32_t k, uint8_t* verdict);
 typedef struct bp_vjob bp_vjob;
 int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uint32_t n_chunks, int host_threads,
                    bp_vjob** out);
@@ -271,7 +293,9 @@ int bp_ipp_prove(bp_ctx* ctx, uint32_t n, const uint8_t* Gs, const uint8_t* Hs, 
  *                   n: the reference's Integer argument (<= 2^20); Gs = bGs (n_gs points), Hs = bHs (n_hs points),
  *                   u = bH, P = commitmentLR; L, R: k points each (zip lCommits rCommits); l, r: 32 bytes each.
  *                   *verdict = 1/0.  Lists shorter than n truncate the sums exactly as `sumExps` does
- *                   (Utils.hs:79); fewer rounds than logBase2 n, where the reference's `!!` fails, is BP_ERR_ARG. */
+ *                   (Utils.hs:79); fewer rounds than logBase2 n, where the reference's `!!` fails, is
+ *                   BP_ERR_REFERENCE_FAILS.  Points that are neither O nor canonical curve points (proof or bases) and
+ *                   l, r >= r do not verify: the reference's types cannot hold them. */
 int bp_ipp_verify(bp_ctx* ctx, uint64_t n, const uint8_t* Gs, uint32_t n_gs, const uint8_t* Hs, uint32_t n_hs,
                   const uint8_t* u, const uint8_t* P, const uint8_t* L, const uint8_t* R, uint32_t k, const uint8_t* l,
                   const uint8_t* r, uint8_t* verdict);

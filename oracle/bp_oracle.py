@@ -327,8 +327,19 @@ def is_log_base2(x):
 
 
 def log_base2(x):
-    """`floor . logBase 2.0 . fromIntegral` (Utils.hs:93-94): Double arithmetic."""
+    """`floor . logBase 2.0 . fromIntegral` (Utils.hs:93-94): Double arithmetic.
+    logBase 2.0 0 is -Infinity and GHC's `floor` of it on Integer is -2^1024
+    (the decoded mantissa shifted by the decoded exponent)."""
+    if x == 0:
+        return -(2**1024)
     return int(math.floor(math.log(float(x)) / math.log(2.0)))
+
+
+def _as_int(x):
+    """`fromIntegral :: Integer -> Int` (64-bit wrap), as `take` / `drop` /
+    `replicate` counts get it (RangeProof/Internal.hs:200, Utils.hs:103)."""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >> 63 else x
 
 
 def log_base2_m(x):
@@ -337,8 +348,10 @@ def log_base2_m(x):
 
 
 def vslice(n, j, vs):
-    """`slice n j vs` (Utils.hs:102-103); j is 1-based."""
-    return vs[(j - 1) * n: j * n]
+    """`slice n j vs` (Utils.hs:102-103); j is 1-based; `take` / `drop` of a
+    non-positive count take / drop nothing."""
+    a = max(_as_int((j - 1) * n), 0)
+    return vs[a: a + max(_as_int(j * n - (j - 1) * n), 0)]
 
 
 def log2_ceil(x):
@@ -399,14 +412,15 @@ def check_ranges(n, vs):
 def hs_prime(y, nm):
     """`hs' = zipWith (\\yi hi -> hi `mul` recip yi) (powerVector y nm) hs`
     (MultiRangeProof/Prover.hs:107, Verifier.hs:85)."""
-    return [point_mul(hi, pow(yi, -1, R)) for yi, hi in zip(power_vector(y, nm), hs(nm))]
+    # `hs` is an infinite list: the zip is as long as powerVector y nm (empty for nm <= 0)
+    return [point_mul(hi, pow(yi, -1, R)) for yi, hi in zip(power_vector(y, nm), hs(max(nm, 0)))]
 
 
 def compute_lr_commitment(n, m, a_commit, s_commit, t, t_blinding, mu, x, y, z, hsp):
     """RangeProof/Internal.hs:169-206."""
     nm = n * m
     gs_sum = O
-    for g in gs(nm):
+    for g in gs(max(_as_int(nm), 0)):          # take (fromIntegral nm) gs   (:200)
         gs_sum = point_add(gs_sum, g)
     h_exp = [z * yi % R for yi in power_vector(y, nm)]
     u = point_mul(GEN, shamir_u(t_blinding, mu, t))
@@ -624,7 +638,9 @@ def verify_lr_commitment(n, m, proof, x, y, z):
     u = point_mul(GEN, shamir_u(proof["tBlinding"], proof["mu"], proof["t"]))
     commitment_lr = compute_lr_commitment(n, m, proof["aCommit"], proof["sCommit"], proof["t"],
                                           proof["tBlinding"], proof["mu"], x, y, z, hsp)
-    return ipp_verify_proof(nm, gs(nm), hsp, u, commitment_lr, proof["productProof"])
+    # bGs = gs is an infinite list (Verifier.hs:80); mkOtherExponents yields at most
+    # max(nm, 1) exponents (keys < nm, and key 0 always), so that prefix is all `sumExps` reads
+    return ipp_verify_proof(nm, gs(max(nm, 1)), hsp, u, commitment_lr, proof["productProof"])
 
 
 def mrp_verify_proof(upper_bound, v_commits, proof):
@@ -634,6 +650,9 @@ def mrp_verify_proof(upper_bound, v_commits, proof):
     x = shamir_x(proof["aCommit"], proof["sCommit"], proof["t1Commit"], proof["t2Commit"], y, z)
     n = log_base2(upper_bound)
     m = len(v_commits)
+    if m == 0:
+        # log2Ceil 0 = -1 (Utils.hs:124-130) and `2 ^ (-1)` raises in GHC
+        raise ArithmeticError("Negative exponent")
     padded = list(v_commits) + [O] * (2**log2_ceil(m) - m)
     m2 = len(padded)
     return verify_t_poly(n, padded, proof, x, y, z) and verify_lr_commitment(n, m2, proof, x, y, z)
