@@ -69,8 +69,8 @@ generateProof circuit@ArithCircuit{..} ArithWitness{..} = do
       withBS (encFrs commitBlinders) $ \pcb ->
       withBS (encFrs [aiBlinding, aoBlinding, sBlinding]) $ \pb3 ->
       withBS (encFrs sL) $ \psl -> withBS (encFrs sR) $ \psr -> withBS (encFrs tRandoms) $ \pt5 ->
-        c_ac_prove ctx (fromIntegral n) (fromIntegral q) (fromIntegral mV) pwl pwr pwo pwv pal par pao pcb pb3 psl psr pt5
-                   psc ppt >>= check "bp_ac_prove"
+        withCtx (\cx -> c_ac_prove cx (fromIntegral n) (fromIntegral q) (fromIntegral mV) pwl pwr pwo pwv pal par pao pcb pb3 psl psr pt5
+                   psc ppt >>= check cx "bp_ac_prove")
     let scalars = BI.fromForeignPtr sc 0 (5 * 32)
         points  = BI.fromForeignPtr pts 0 (npts * 64)
         sAt i = decFr (BS.take 32 (BS.drop (32 * i) scalars))
@@ -96,6 +96,6 @@ verifyProof vCommits ArithCircuitProof{..} circuit@ArithCircuit{..} = unsafePerf
     withBS (encMatrix wL) $ \pwl -> withBS (encMatrix wR) $ \pwr -> withBS (encMatrix wO) $ \pwo ->
     withBS (encMatrix commitmentWeights) $ \pwv -> withBS (encFrs cs) $ \pcs ->
     withBS (encPts (take mV vCommits)) $ \pvc -> withBS scalars $ \psc -> withBS points $ \ppt ->
-      c_ac_verify ctx (fromIntegral n) (fromIntegral q) (fromIntegral mV) pwl pwr pwo pwv pcs pvc psc ppt po
-        >>= check "bp_ac_verify"
+      withCtx (\cx -> c_ac_verify cx (fromIntegral n) (fromIntegral q) (fromIntegral mV) pwl pwr pwo pwv pcs pvc psc ppt po
+        >>= check cx "bp_ac_verify")
   pure (BS.head out /= 0)

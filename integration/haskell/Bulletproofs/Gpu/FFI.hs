@@ -13,9 +13,9 @@
 --   Bulletproofs.Gpu.RangeProof         generateProof(Unsafe), verifyProof         (Bulletproofs/RangeProof.hs:1-8)
 --   Bulletproofs.Gpu.ArithmeticCircuit  generateProof, verifyProof                 (Bulletproofs/ArithmeticCircuit.hs:1-10)
 module Bulletproofs.Gpu.FFI
-  ( BpCtx, ctx, maxGenerators
+  ( BpCtx, withCtx, maxGenerators, errReferenceFails
   , c_msm, c_add_two_mul, c_point_mul, c_point_add, c_point_neg
-  , c_upper_bound_bits, c_log_base2, c_rangeproof_prove, c_rangeproof_verify_batch
+  , c_upper_bound_bits, c_log_base2, c_rangeproof_prove, c_rangeproof_verify_batch, c_rangeproof_verify
   , c_ipp_prove, c_ipp_verify, c_ac_proof_points, c_ac_prove, c_ac_verify
   , c_generators_derive, c_generators_load, c_generators_save, c_show_numbers, c_last_error
   , encFr, encFrs, encPt, encPts, decFr, decPt, decPts, withBS, check, leBytes
@@ -29,6 +29,7 @@ import Foreign
 import Foreign.C.String (CString, peekCString)
 import Foreign.C.Types
 import System.IO.Unsafe (unsafePerformIO)
+import Control.Concurrent.MVar (MVar, newMVar, withMVar)
 
 import Data.Curve.Weierstrass.SECP256K1 (PA, Fr)
 import Data.Curve.Weierstrass (Point(..))
@@ -54,6 +55,8 @@ foreign import ccall safe "bp_rangeproof_prove"  c_rangeproof_prove
   -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> CInt -> Ptr Word8 -> Ptr Word8 -> IO CInt
 foreign import ccall safe "bp_rangeproof_verify_batch" c_rangeproof_verify_batch
   :: Ptr BpCtx -> Word32 -> Word32 -> Word32 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> IO CInt
+foreign import ccall safe "bp_rangeproof_verify" c_rangeproof_verify
+  :: Ptr BpCtx -> Ptr Word8 -> CSize -> Ptr Word8 -> Word32 -> Ptr Word8 -> Ptr Word8 -> Word32 -> Ptr Word8 -> IO CInt
 foreign import ccall safe "bp_ipp_prove"         c_ipp_prove
   :: Ptr BpCtx -> Word32 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8
   -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> Ptr Word8 -> IO CInt
@@ -77,15 +80,32 @@ maxGenerators = 8192
 -- | One context per process, like the reference's CAF generator lists (Utils.hs:14-25).  The host application
 -- exports GPU_MAX_HW_QUEUES=16 before anything initialises HIP (INTEGRATION.md section 5); the library itself never
 -- touches the environment.
-{-# NOINLINE ctx #-}
-ctx :: Ptr BpCtx
-ctx = unsafePerformIO $ alloca $ \pp -> do
-  rc <- c_ctx_create pp 0
-  when (rc /= 0) $ panic "bp_ctx_create failed"
-  c <- peek pp
-  rc' <- c_generators_derive c (fromIntegral maxGenerators) nullPtr nullPtr nullPtr
-  when (rc' /= 0) $ panic "bp_generators_derive failed"
-  pure c
+--
+-- A context is NOT thread-safe (include/bpgpu.h: one stream, grow-only workspaces and a cached verify job that calls
+-- replace), and the drop-ins are pure functions that a -threaded program may force from several capabilities at once
+-- (`parMap verifyProof`).  Every call on the context therefore goes through `withCtx`, which holds a process-wide
+-- lock for the duration of the foreign call AND of the error-message read that may follow it.  The reference is
+-- single-threaded, so serialising the calls loses nothing it had; concurrency inside a call (the batch verifier's
+-- chunks and hashing threads) is the library's own.
+{-# NOINLINE ctxVar #-}
+ctxVar :: MVar (Ptr BpCtx)
+ctxVar = unsafePerformIO $ do
+  c <- alloca $ \pp -> do
+    rc <- c_ctx_create pp 0
+    when (rc /= 0) $ panic "bp_ctx_create failed"
+    c <- peek pp
+    rc' <- c_generators_derive c (fromIntegral maxGenerators) nullPtr nullPtr nullPtr
+    when (rc' /= 0) $ panic "bp_generators_derive failed"
+    pure c
+  newMVar c
+
+-- | Run one engine call with the process-wide context, exclusively.  Do not nest.
+withCtx :: (Ptr BpCtx -> IO a) -> IO a
+withCtx = withMVar ctxVar
+
+-- | BP_ERR_REFERENCE_FAILS (include/bpgpu.h): the reference's own evaluation raises on these arguments.
+errReferenceFails :: CInt
+errReferenceFails = -8
 
 ---------------------------------------------------------------------------------------------------
 -- Marshalling: Fr <-> 32 bytes little-endian, PA <-> 64 bytes x || y little-endian, O <-> 64 zero bytes
@@ -126,7 +146,8 @@ withBS bs k
   | BS.null bs = allocaBytes 1 k
   | otherwise  = BU.unsafeUseAsCString bs (k . castPtr)
 
-check :: Text -> CInt -> IO ()
-check what rc = when (rc /= 0) $ do
-  msg <- c_last_error ctx >>= peekCString
+-- | Inside `withCtx`: turn a non-zero status of the call just made on `c` into a `panic` carrying the library's message.
+check :: Ptr BpCtx -> Text -> CInt -> IO ()
+check c what rc = when (rc /= 0) $ do
+  msg <- c_last_error c >>= peekCString
   panic (what <> " failed (" <> show rc <> "): " <> toS msg)

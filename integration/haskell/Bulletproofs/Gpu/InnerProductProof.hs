@@ -31,7 +31,7 @@ generateProof InnerProductBase{ bGs, bHs, bH } commitmentLR InnerProductWitness{
     withBS (encPts (take n bGs)) $ \pg -> withBS (encPts (take n bHs)) $ \ph ->
     withBS (encPt bH) $ \pu -> withBS (encPt commitmentLR) $ \pp ->
     withBS (encFrs ls) $ \pls -> withBS (encFrs (take n rs)) $ \prs ->
-      c_ipp_prove ctx (fromIntegral n) pg ph pu pp pls prs pL pR pl (pl `plusPtr` 32) >>= check "bp_ipp_prove"
+      withCtx (\cx -> c_ipp_prove cx (fromIntegral n) pg ph pu pp pls prs pL pR pl (pl `plusPtr` 32) >>= check cx "bp_ipp_prove")
   let lr = BI.fromForeignPtr lrBuf 0 64
   pure InnerProductProof
     { lCommits = decPts k (BI.fromForeignPtr lBuf 0 (64 * k))
@@ -50,6 +50,6 @@ verifyProof n InnerProductBase{ bGs, bHs, bH } commitmentLR InnerProductProof{ l
       withBS (encPt bH) $ \pu -> withBS (encPt commitmentLR) $ \pp ->
       withBS (encPts (take k lCommits)) $ \pL -> withBS (encPts (take k rCommits)) $ \pR ->
       withBS (encFr l) $ \pl -> withBS (encFr r) $ \pr ->
-        c_ipp_verify ctx (fromIntegral n) pg (fromIntegral (length bGs)) ph (fromIntegral (length bHs)) pu pp
-                     pL pR (fromIntegral k) pl pr po >>= check "bp_ipp_verify"
+        withCtx (\cx -> c_ipp_verify cx (fromIntegral n) pg (fromIntegral (length bGs)) ph (fromIntegral (length bHs)) pu pp
+                     pL pR (fromIntegral k) pl pr po >>= check cx "bp_ipp_verify")
     pure (BS.head out /= 0)

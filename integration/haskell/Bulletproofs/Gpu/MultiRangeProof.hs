@@ -1,7 +1,7 @@
 {-# LANGUAGE RecordWildCards, ScopedTypeVariables #-}
 -- | Drop-in for Bulletproofs.MultiRangeProof (Bulletproofs/MultiRangeProof.hs:1-8): `generateProof`,
--- `generateProofUnsafe`, `verifyProof` with the reference's types, plus `verifyProofs` = `map verifyProof` as one
--- batched call.  The MonadRandom draws stay in Haskell, in the reference's order, and only happen after the
+-- `generateProofUnsafe`, `verifyProof` with the reference's types (and the reference's totality: see `verifyProof`),
+-- plus `verifyProofs` = `map verifyProof` as one batched call.  The MonadRandom draws stay in Haskell, in the reference's order, and only happen after the
 -- validation of `generateProof` has passed, exactly as in MultiRangeProof/Prover.hs:25-43.
 -- NOT COMPILED here (no GHC in the build image).
 module Bulletproofs.Gpu.MultiRangeProof
@@ -23,7 +23,7 @@ import Data.Curve.Weierstrass (Point(..))
 
 import Bulletproofs.RangeProof.Internal
 import Bulletproofs.InnerProductProof.Internal (InnerProductProof(..))
-import Bulletproofs.Utils (logBase2, logBase2M, log2Ceil, chooseBlindingVectors)
+import Bulletproofs.Utils (logBase2, logBase2M, isLogBase2, log2Ceil, chooseBlindingVectors)
 import Bulletproofs.Gpu.FFI
 
 -- | MultiRangeProof/Prover.hs:19-43, control flow unchanged: the three guards, then the padding with (0, 0).
@@ -76,8 +76,8 @@ generateProofUnsafe upperBound vsAndvBlindings = do
       withBS (encFrs sL) $ \psl -> withBS (encFrs sR) $ \psr ->
       withBS (encFr aBlinding) $ \pa -> withBS (encFr sBlinding) $ \pr ->
       withBS (encFr t1Blinding) $ \p1 -> withBS (encFr t2Blinding) $ \p2 ->
-        c_rangeproof_prove ctx (fromIntegral n) (fromIntegral m) pv pg psl psr pa pr p1 p2 0 psc ppt
-          >>= check "bp_rangeproof_prove"
+        withCtx (\cx -> c_rangeproof_prove cx (fromIntegral n) (fromIntegral m) pv pg psl psr pa pr p1 p2 0 psc ppt
+                          >>= check cx "bp_rangeproof_prove")
     let scalars = BI.fromForeignPtr sc 0 (5 * 32)
         points  = BI.fromForeignPtr pts 0 ((4 + 2 * k) * 64)
         sAt i = decFr (BS.take 32 (BS.drop (32 * i) scalars))
@@ -88,22 +88,51 @@ generateProofUnsafe upperBound vsAndvBlindings = do
       , productProof = InnerProductProof
           { lCommits = pAt <$> [4 .. 3 + k], rCommits = pAt <$> [4 + k .. 3 + 2 * k], l = sAt 3, r = sAt 4 } }
 
--- | MultiRangeProof/Verifier.hs:19-39.
+-- | MultiRangeProof/Verifier.hs:19-39, total like the reference's function: any `upperBound` (n = logBase2 upperBound is
+-- whatever Double arithmetic gives, Utils.hs:93-94), any number of commitments, any number of L/R pairs in the proof.
+-- bp_rangeproof_verify routes honest-shape proofs to the batch engine and follows the reference's definitions
+-- literally for everything else (prop_differentUpperBound, test/Test/Protocol/RangeProof.hs:173-181).  Where the
+-- reference's evaluation raises (`challenges !! j` with too few pairs once verifyTPoly holds, `2 ^ (-1)` for no
+-- commitments) the library answers BP_ERR_REFERENCE_FAILS and this raises too; no Bool is invented.
 verifyProof :: Integer -> [PA] -> RangeProof Fr PA -> Bool
-verifyProof upperBound vCommits proof = and (verifyProofs upperBound [(vCommits, proof)])
+verifyProof upperBound vCommits RangeProof{..} = unsafePerformIO $ do
+  let InnerProductProof{..} = productProof
+      k       = min (length lCommits) (length rCommits)     -- zip lCommits rCommits (InnerProductProof/Verifier.hs:53)
+      ub      = leBytes (max 1 (byteLength upperBound)) (max 0 upperBound)
+      scalars = encFrs [tBlinding, mu, t, l, r]
+      points  = encPts ([aCommit, sCommit, t1Commit, t2Commit] <> take k lCommits <> take k rCommits)
+  when (upperBound < 0) $ panic "verifyProof: negative upper bound (logBase2 of a negative number is NaN)"
+  out <- BI.create 1 $ \po -> withBS ub $ \pu -> withBS (encPts vCommits) $ \pv ->
+    withBS scalars $ \ps -> withBS points $ \pp ->
+      withCtx (\cx -> c_rangeproof_verify cx pu (fromIntegral (BS.length ub)) pv (fromIntegral (length vCommits)) ps pp
+                                          (fromIntegral k) po >>= check cx "bp_rangeproof_verify")
+  pure (BS.head out /= 0)
+  where
+    byteLength :: Integer -> Int
+    byteLength v = length (takeWhile (> 0) (iterate (`div` 256) v))
 
--- | `map (\(vs, p) -> verifyProof upperBound vs p)` as one batch: all proofs must share the upper bound and the
--- padded number of commitments.  The verdicts are per proof (no random linear combination across proofs).
+-- | `map (\(vs, p) -> verifyProof upperBound vs p)` with the honest-shape proofs of the list verified as ONE batched
+-- call.  The batch engine takes one shape per call: n = logBase2 upperBound a power of two <= 128, the commitments
+-- padded to m2 = 2 ^ log2Ceil (length vs) of the first proof, and exactly k = log2Ceil (n * m2) L/R pairs (what
+-- generateProofUnsafe produces).  A proof of any other shape - another padded commitment count, lCommits or rCommits
+-- of another length, or any proof at all when n is outside the engine's domain - is never sent with the batch (the
+-- library would read its rows at the wrong offsets): it goes through `verifyProof` above, one call each, which is
+-- total.  The verdicts are per proof (no random linear combination across proofs) and come back in list order.
 verifyProofs :: Integer -> [([PA], RangeProof Fr PA)] -> [Bool]
 verifyProofs _ [] = []
-verifyProofs upperBound batch@((vs0, p0) : _) = unsafePerformIO $ do
-  let n      = logBase2 upperBound                          -- Verifier.hs:34
-      m      = 2 ^ log2Ceil (length vs0) :: Int             -- padding with mempty, Verifier.hs:37-38
-      b      = length batch
-      proofs = snd <$> batch
-      row f  = BS.concat (f <$> proofs)
-      ipp    = productProof
-      k      = length (lCommits (ipp p0))
+verifyProofs upperBound batch@((vs0, _) : _) = unsafePerformIO $ do
+  let n       = logBase2 upperBound                          -- Verifier.hs:34
+      nOk     = upperBound > 0 && n >= 1 && n <= 128 && isLogBase2 n
+      m       = if null vs0 then 0 else 2 ^ log2Ceil (length vs0) :: Int   -- padding with mempty, Verifier.hs:37-38
+      k       = log2Ceil (fromIntegral n * m)                -- as generateProofUnsafe, MultiRangeProof/Prover.hs
+      ipp     = productProof
+      fits (vs, p) = nOk && m >= 1 && not (null vs) && 2 ^ log2Ceil (length vs) == m
+                     && length (lCommits (ipp p)) == k && length (rCommits (ipp p)) == k
+      tagged  = [ (fits e, e) | e <- batch ]
+      inBatch = [ e | (True, e) <- tagged ]
+      b       = length inBatch
+      proofs  = snd <$> inBatch
+      row f   = BS.concat (f <$> proofs)
       at xs i = fromMaybe O (atMay xs i)
       scalars = BS.concat [ row (encFr . tBlinding), row (encFr . mu), row (encFr . t)
                           , row (encFr . l . ipp), row (encFr . r . ipp) ]
@@ -111,8 +140,15 @@ verifyProofs upperBound batch@((vs0, p0) : _) = unsafePerformIO $ do
                   [ row (encPt . aCommit), row (encPt . sCommit), row (encPt . t1Commit), row (encPt . t2Commit) ]
                   <> [ row (\p -> encPt (lCommits (ipp p) `at` i)) | i <- [0 .. k - 1] ]
                   <> [ row (\p -> encPt (rCommits (ipp p) `at` i)) | i <- [0 .. k - 1] ]
-                  <> [ BS.concat [ encPt (vs `at` j) | (vs, _) <- batch ] | j <- [0 .. m - 1] ]
-  out <- BI.create b $ \po -> withBS scalars $ \ps -> withBS points $ \pp ->
-    c_rangeproof_verify_batch ctx (fromIntegral n) (fromIntegral m) (fromIntegral b) ps pp po
-      >>= check "bp_rangeproof_verify_batch"
-  pure ((/= 0) <$> BS.unpack out)
+                  <> [ BS.concat [ encPt (vs `at` j) | (vs, _) <- inBatch ] | j <- [0 .. m - 1] ]
+  batched <- if b == 0 then pure [] else do
+    out <- BI.create b $ \po -> withBS scalars $ \ps -> withBS points $ \pp ->
+      withCtx (\cx -> c_rangeproof_verify_batch cx (fromIntegral n) (fromIntegral m) (fromIntegral b) ps pp po
+                        >>= check cx "bp_rangeproof_verify_batch")
+    pure ((/= 0) <$> BS.unpack out)
+  -- merge back in list order; the out-of-shape proofs are evaluated lazily, one total call each
+  let merge [] _ = []
+      merge ((True, _) : rest) (v : vs) = v : merge rest vs
+      merge ((True, _) : _) [] = panic "verifyProofs: verdict count"
+      merge ((False, (vs, p)) : rest) vsB = verifyProof upperBound vs p : merge rest vsB
+  pure (merge tagged batched)

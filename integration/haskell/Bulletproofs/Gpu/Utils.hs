@@ -20,7 +20,7 @@ sumExps es ps = unsafePerformIO $ do
   out <- BI.create 64 $ \po ->
     withBS (encFrs (take n es)) $ \pe ->
     withBS (encPts (take n ps)) $ \pp ->
-      c_msm ctx pe pp (fromIntegral n) po >>= check "bp_msm"
+      withCtx (\cx -> c_msm cx pe pp (fromIntegral n) po >>= check cx "bp_msm")
   pure (decPt out)
 
 -- | `addTwoMulP` (Utils.hs:72-73): e0 * p0 + e1 * p1.
@@ -28,7 +28,7 @@ addTwoMulP :: Fr -> PA -> Fr -> PA -> PA
 addTwoMulP e0 p0 e1 p1 = unsafePerformIO $ do
   out <- BI.create 64 $ \po ->
     withBS (encFr e0) $ \a -> withBS (encPt p0) $ \b -> withBS (encFr e1) $ \c -> withBS (encPt p1) $ \d ->
-      c_add_two_mul ctx a b c d 1 po >>= check "bp_add_two_mul"
+      withCtx (\cx -> c_add_two_mul cx a b c d 1 po >>= check cx "bp_add_two_mul")
   pure (decPt out)
 
 -- | `commit x r = addTwoMulP x gen r h` (Utils.hs:84-85): the reference's type, its own `gen` and `h`.
@@ -42,5 +42,5 @@ mulPs ps es = unsafePerformIO $ do
   let n = min (length es) (length ps)
   out <- BI.create (64 * n) $ \po ->
     withBS (encFrs (take n es)) $ \pe -> withBS (encPts (take n ps)) $ \pp ->
-      c_point_mul ctx pe pp (fromIntegral n) po >>= check "bp_point_mul"
+      withCtx (\cx -> c_point_mul cx pe pp (fromIntegral n) po >>= check cx "bp_point_mul")
   pure (decPts n out)

@@ -93,7 +93,7 @@ def test_every_foreign_import_matches_the_header():
 def test_the_bindings_cover_the_entry_points_the_drop_in_needs():
     bound = {sym for _, sym, _, _ in foreign_imports()}
     need = {"bp_ctx_create", "bp_generators_derive", "bp_msm", "bp_add_two_mul", "bp_point_mul",
-            "bp_rangeproof_prove", "bp_rangeproof_verify_batch", "bp_ipp_prove", "bp_ipp_verify", "bp_ac_prove",
+            "bp_rangeproof_prove", "bp_rangeproof_verify_batch", "bp_rangeproof_verify", "bp_ipp_prove", "bp_ipp_verify", "bp_ac_prove",
             "bp_ac_verify", "bp_upper_bound_bits", "bp_log_base2"}
     assert need <= bound, "missing bindings: %s" % sorted(need - bound)
 
@@ -148,3 +148,45 @@ def test_range_check_precedes_the_draws():
     order = [unsafe.index(s) for s in ("chooseBlindingVectors nm", "aBlinding  <-", "sBlinding  <-", "t1Blinding <-",
                                        "t2Blinding <-")]
     assert order == sorted(order)
+
+
+def _code(fname):
+    return re.sub(r"--.*$", "", hs_sources()[fname], flags=re.M)
+
+
+def test_every_context_call_holds_the_process_wide_lock():
+    """include/bpgpu.h: a context is not thread-safe.  The drop-ins are pure functions a -threaded program may force
+    concurrently, so every foreign call that takes the context runs inside `withCtx` (an MVar), together with the
+    error-message read that may follow it; nothing outside FFI.hs can name the raw context."""
+    ffi = _code("FFI.hs")
+    exports = ffi[ffi.index("module Bulletproofs.Gpu.FFI"):ffi.index(") where")]
+    assert "withCtx" in exports and not re.search(r"\bctx\b", exports) and "ctxVar" not in exports
+    assert re.search(r"withCtx\s*=\s*withMVar ctxVar", ffi)
+    ctx_taking = {ident for _, sym, ident, sig in foreign_imports() if sig.startswith("Ptr BpCtx")}
+    assert "c_rangeproof_verify" in ctx_taking and "c_msm" in ctx_taking
+    for fname in hs_sources():
+        if fname == "FFI.hs":
+            continue
+        text = _code(fname)
+        assert not re.search(r"\bctx\b", text), "%s names the raw context" % fname
+        for ident in ctx_taking:
+            for m in re.finditer(r"\b%s\b" % ident, text):
+                before = text[max(0, m.start() - 40):m.start()]
+                assert re.search(r"withCtx \(\\cx -> $", before), "%s: %s is called outside withCtx" % (fname, ident)
+                assert text[m.end():m.end() + 4] == " cx ", "%s: %s does not get the locked context" % (fname, ident)
+
+
+def test_batched_verify_never_sizes_its_buffers_from_a_proof():
+    """bp_rangeproof_verify_batch reads 4 + 2 log2(n m) + m rows whatever the proof holds, so the shim
+    takes k from the shape (as generateProofUnsafe does), sends only proofs whose lCommits AND rCommits have exactly
+    that length and whose commitments pad to the same m, and gives every other proof to the total verifyProof."""
+    text = _code("MultiRangeProof.hs")
+    body = text[text.index("verifyProofs upperBound batch@"):]
+    assert re.search(r"k\s*=\s*log2Ceil \(fromIntegral n \* m\)", body)
+    assert "length (lCommits (ipp p)) == k && length (rCommits (ipp p)) == k" in body
+    assert "2 ^ log2Ceil (length vs) == m" in body
+    assert "isLogBase2 n" in body and "n <= 128" in body
+    assert "verifyProof upperBound vs p" in body            # the out-of-shape proofs
+    single = text[text.index("verifyProof upperBound vCommits RangeProof{..}"):text.index("verifyProofs\n" if False else "verifyProofs ::")]
+    assert "c_rangeproof_verify cx" in single and "min (length lCommits) (length rCommits)" in single
+    assert "panic" not in single.replace('panic "verifyProof: negative upper bound', "")  # total: no shape panics
