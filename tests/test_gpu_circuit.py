@@ -156,30 +156,46 @@ def test_unsatisfied_circuit_is_rejected(eng_gens):
     assert o.ac_verify_proof(witness["commitments"], exp, circuit) is False
 
 
-def test_config5_shape_round_trip(engine):
-    """SURVEY 8d config 5 at full size: n = 2^12 gates, Q = 2 dense rows; completeness and
-    soundness-on-mutation as size-independent properties (the Python oracle needs minutes here)."""
-    n = 4096
+def test_config5_full_size_vs_oracle_fixture(engine):
+    """BASELINE config 5 at FULL size (n = 2^12 gates, Q = 2) against the oracle: tests/golden/config5_vectors.json
+    holds what oracle/bp_oracle.py (ArithmeticCircuit/Prover.hs:16-117, Verifier.hs:16-71) computed for the seed-5
+    inputs of util.config5_inputs - the whole proof (34 points + 5 scalars), a SHA-256 over the points, and the verdicts
+    of the honest proof and three mutations (tests/golden/make_golden_config5.py; ~7 minutes of Python).  bp_ac_prove
+    must return that proof byte for byte and bp_ac_verify those verdicts."""
+    import hashlib
+    import json
+    import os
+    from util import HERE, config5_inputs, config5_mutations, ux, up
+    with open(os.path.join(HERE, "golden", "config5_vectors.json")) as f:
+        g = json.load(f)
+    n = g["n"]
     engine.derive_generators(n)
-    rng = random.Random(5)
-    a_l = [rng.randrange(R) for _ in range(n)]
-    a_r = [rng.randrange(R) for _ in range(n)]
-    r, s = rng.randrange(R), rng.randrange(R)
-    circuit = dict(wL=[[1] * n, [0] * n], wR=[[0] * n, [1] * n], wO=[[0] * n, [0] * n],
-                   commitmentWeights=[[1, 0], [0, 1]], cs=[0, 0])
-    v0, v1 = sum(a_l) % R, sum(a_r) % R
-    commitments = engine.add_two_mul_p([v0, v1], [o.GEN] * 2, [r, s], [o.h()] * 2)
-    witness = dict(assignment=dict(aL=a_l, aR=a_r, aO=o.hadamard(a_l, a_r)), commitments=commitments,
-                   commitBlinders=[r, s])
-    three = [rng.randrange(1, R) for _ in range(3)]
-    s_l = [rng.randrange(1, R) for _ in range(n)]
-    s_r = [rng.randrange(1, R) for _ in range(n)]
-    five = [rng.randrange(1, R) for _ in range(5)]
-    proof = engine.ac_prove(circuit, witness, *three, s_l, s_r, five)
-    assert len(proof["productProof"]["lCommits"]) == 12
-    assert engine.ac_verify(commitments, proof, circuit) is True
-    assert engine.ac_verify(commitments, dict(proof, t=(proof["t"] + 1) % R), circuit) is False
-    assert engine.ac_verify([commitments[1], commitments[0]], proof, circuit) is False
+    circuit, witness, openings, blinders = config5_inputs(o, n, g["seed"])
+    commitments = engine.add_two_mul_p([v for v, _ in openings], [o.GEN] * 2, [b for _, b in openings], [o.h()] * 2)
+    assert commitments == [up(p) for p in g["commitments"]]
+    witness = dict(witness, commitments=commitments)
+    pj = g["proof"]
+    want = dict(tBlinding=ux(pj["tBlinding"]), mu=ux(pj["mu"]), t=ux(pj["t"]), aiCommit=up(pj["aiCommit"]),
+                aoCommit=up(pj["aoCommit"]), sCommit=up(pj["sCommit"]), tCommits=[up(p) for p in pj["tCommits"]],
+                productProof=dict(lCommits=[up(p) for p in pj["lCommits"]], rCommits=[up(p) for p in pj["rCommits"]],
+                                  l=ux(pj["l"]), r=ux(pj["r"])))
+    got = engine.ac_prove(circuit, witness, *blinders)
+    assert len(got["productProof"]["lCommits"]) == 12
+    ipp = got["productProof"]
+    pts = [got["aiCommit"], got["aoCommit"], got["sCommit"]] + list(got["tCommits"]) + list(ipp["lCommits"]) \
+        + list(ipp["rCommits"])
+    assert hashlib.sha256(b"".join(o.wire_point(p) for p in pts)).hexdigest() == g["points_sha256"]
+    assert got == want
+    # the transcript values the oracle saw on the way (host layer of the engine against the fixture)
+    from bulletproofs_amd import _lib
+    assert _lib.transcript(0, 7, pts=[got["aiCommit"], got["aoCommit"], got["sCommit"]]) == ux(g["y"])
+    assert _lib.transcript(0, 8, scs=[ux(g["y"])]) == ux(g["z"])
+    assert _lib.transcript(0, 9, pts=got["tCommits"], raw=b"x" * 7) == ux(g["x"])
+    assert engine.mul([o.GEN], [o.shamir_u(want["tBlinding"], want["mu"], want["t"])])[0] == up(g["u"])
+    v = g["verdicts"]
+    assert engine.ac_verify(commitments, want, circuit) is v["honest"] is True
+    verdicts = [engine.ac_verify(bc, bp, circuit) for bp, bc in config5_mutations(o, want, commitments)]
+    assert verdicts == [v["t_plus_1"], v["commitments_swapped"], v["l0_r0_swapped"]] == [False, False, False]
     engine.set_generators(o.gs(128), o.hs(128), o.h())
 
 

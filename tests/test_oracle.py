@@ -264,3 +264,66 @@ def test_circuit_completeness_on_reference_circuits():
     pr = o.ac_generate_proof(circuit, witness, *o.ac_draw_blinders(rng, 1))
     assert o.ac_verify_proof([], pr, circuit)
     assert not o.ac_verify_proof([], pr, dict(circuit, cs=[36, 5, 7]))
+
+
+def test_config5_fixture_is_consistent():
+    """tests/golden/config5_vectors.json (config 5 at full size, written by make_golden_config5.py): the stored
+    challenges are the oracle's transcript of the stored proof points, the digest is over those points, and the inputs
+    the GPU test regenerates from the seed have the stored commitments' openings (cheap checks only: the full
+    prove / verify takes the oracle minutes and is what the generator script ran)."""
+    import hashlib
+    import json
+    import os
+    from util import HERE, config5_inputs, ux, up
+    with open(os.path.join(HERE, "golden", "config5_vectors.json")) as f:
+        g = json.load(f)
+    pj = g["proof"]
+    ai, ao, s = up(pj["aiCommit"]), up(pj["aoCommit"]), up(pj["sCommit"])
+    tcs = [up(p) for p in pj["tCommits"]]
+    ls, rs = [up(p) for p in pj["lCommits"]], [up(p) for p in pj["rCommits"]]
+    assert len(ls) == len(rs) == 12 and len(tcs) == 7
+    y = o.shamir_gxgxg(ai, ao, s)
+    assert y == ux(g["y"]) and o.ac_shamir_z(y) == ux(g["z"]) and o.shamir_gs(tcs) == ux(g["x"])
+    assert o.point_mul(o.GEN, o.shamir_u(ux(pj["tBlinding"]), ux(pj["mu"]), ux(pj["t"]))) == up(g["u"])
+    pts = [ai, ao, s] + tcs + ls + rs
+    assert all(o.is_on_curve(p) for p in pts)
+    assert hashlib.sha256(b"".join(o.wire_point(p) for p in pts)).hexdigest() == g["points_sha256"]
+    _, _, openings, _ = config5_inputs(o, g["n"], g["seed"])
+    assert [o.commit(v, b) for v, b in openings] == [up(p) for p in g["commitments"]]
+    assert g["verdicts"] == dict(honest=True, t_plus_1=False, commitments_swapped=False, l0_r0_swapped=False)
+
+
+def test_verifier_is_total_over_bounds_and_pair_counts():
+    """MultiRangeProof/Verifier.hs:25-39 checks neither the bound nor the proof's shape: the oracle follows it for
+    bounds that are no power of two, n = 0 (and upperBound = 0, whose logBase2 GHC floors to -2^1024), surplus L/R
+    pairs, and raises where `challenges !! j` (InnerProductProof/Verifier.hs:72) or `2 ^ log2Ceil 0` would."""
+    rng = random.Random(41)
+    vs = [(rng.randrange(0, 2**8), rng.randrange(1, o.R))]
+    pr = o.mrp_generate_proof(2**8, vs, *o.draw_blinders(rng, 8))
+    vcs = [o.commit(*vs[0])]
+    assert o.log_base2(0) == -(2**1024) and o.log_base2(12) == 3 and o.log_base2(2**64 - 1) == 64
+    for ub in (2**4, 2**16, 12, 1, 0, 2**7, 3):          # prop_differentUpperBound: verifyTPoly fails first
+        assert o.mrp_verify_proof(ub, vcs, pr) is False
+    assert o.mrp_verify_proof(2**8 + 1, vcs, pr) is True  # logBase2 floors: still n = 8
+    y = o.shamir_y(pr["aCommit"], pr["sCommit"])
+    z = o.shamir_z(pr["aCommit"], pr["sCommit"], y)
+    for ub, want in ((12, False), (2**4, False), (1, False), (0, False), (2**16, IndexError)):
+        n2 = o.log_base2(ub)
+        f = dict(pr, t=(pr["t"] - o.delta(8, 1, y, z) + o.delta(n2, 1, y, z)) % o.R)  # verifyTPoly holds under ub
+        if want is IndexError:
+            with pytest.raises(IndexError):
+                o.mrp_verify_proof(ub, vcs, f)
+        else:
+            assert o.mrp_verify_proof(ub, vcs, f) is want
+    ipp = pr["productProof"]
+    longer = dict(pr, productProof=dict(ipp, lCommits=ipp["lCommits"] + [o.GEN], rCommits=ipp["rCommits"] + [o.GEN]))
+    assert o.mrp_verify_proof(2**8, vcs, longer) is False
+    with pytest.raises(IndexError):
+        o.mrp_verify_proof(2**8, vcs, dict(pr, productProof=dict(ipp, lCommits=ipp["lCommits"][:-1])))
+    with pytest.raises(ArithmeticError):
+        o.mrp_verify_proof(2**8, [], pr)
+    # n m = 0: mkOtherExponents still holds key 0 and bGs = gs is infinite, so gsCommit = s0 * gs!!0
+    assert o.mk_other_exponents(0, [5, 7]) == [pow(35, -1, o.R)]
+    assert o.mk_other_exponents(12, [2, 3, 5])[:3] == [pow(30, -1, o.R), pow(30, -1, o.R) * 4 % o.R,
+                                                      pow(30, -1, o.R) * 9 % o.R]
+    assert len(o.mk_other_exponents(12, [2, 3, 5])) == 10  # keys 10, 11 are never inserted: sumExps truncates
