@@ -42,9 +42,14 @@ def main():
         d_p = torch.from_numpy(pts.copy()).cuda()
         d_o = torch.zeros(64, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
+        eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, d_o.data_ptr(), 0)
+        eng.sync()
+        ref = bytes(d_o.cpu().numpy())
         for _ in range(2):
             eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, d_o.data_ptr(), a.c)
         eng.sync()
+        if bytes(d_o.cpu().numpy()) != ref:
+            raise SystemExit("window_bits = %d gives another point than the default plan at 2^%d" % (a.c, logn))
         t0 = time.perf_counter()
         for _ in range(a.iters):
             eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, d_o.data_ptr(), a.c)

@@ -202,33 +202,69 @@ __global__ void __launch_bounds__(1024) k_recode_coarse(const uint8_t* __restric
     if (lh[k]) atomicAdd(&chist[k], lh[k]);
 }
 
-// cstart = exclusive scan of chist over the cnt (window, bin) counters; ccur = cstart
+// cstart = exclusive scan of chist over the cnt (window, bin) counters; ccur = cstart.
+// Also cuts every bin into tiles of FINE_TILE entries for the fine sort below: tile_start[k] = first tile of bin k
+// (tile_start[cnt] = number of tiles), tile_bin[t] = the bin tile t belongs to.  A uniform 2^20-point sum has ~8,192
+// entries a bin (two tiles); structured scalars pile half a million entries onto ONE bin ({0,1} scalars: digit 1 of
+// window 0; 64-bit scalars: the carry digit behind their top window), which a single workgroup took 1 ms to sort.
+constexpr uint32_t FINE_TILE = 4096;
+// every bin owns at least one tile (an empty bin's tile just stores its buckets' starts), so tile_start is strictly
+// increasing; the tiles of a call number at most (bins) + (entries) / FINE_TILE
+__host__ __device__ inline uint32_t fine_tiles(uint32_t c) { return c ? (c + FINE_TILE - 1) / FINE_TILE : 1u; }
 __global__ void __launch_bounds__(1024) k_coarse_scan(const uint32_t* __restrict__ chist, uint32_t cnt,
-                                                     uint32_t* __restrict__ cstart, uint32_t* __restrict__ ccur) {
-  __shared__ uint32_t part[1024];
+                                                     uint32_t* __restrict__ cstart, uint32_t* __restrict__ ccur,
+                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_bin,
+                                                     uint32_t max_tiles) {
+  __shared__ uint32_t part[1024], tpart[1024];
+  __shared__ uint32_t ts[CO_MAXCNT + 1];
   const int t = threadIdx.x;
   const uint32_t per = (cnt + 1023) / 1024;
-  uint32_t sum = 0;
-  for (uint32_t k = 0; k < per; k++) {
-    uint32_t b = t * per + k;
-    if (b < cnt) sum += chist[b];
-  }
-  part[t] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint32_t v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[t] - sum;
+  uint32_t sum = 0, tsum = 0;
   for (uint32_t k = 0; k < per; k++) {
     uint32_t b = t * per + k;
     if (b < cnt) {
+      const uint32_t c = chist[b];
+      sum += c;
+      tsum += fine_tiles(c);
+    }
+  }
+  part[t] = sum;
+  tpart[t] = tsum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0, tv = t >= d ? tpart[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    tpart[t] += tv;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum, trun = tpart[t] - tsum;
+  for (uint32_t k = 0; k < per; k++) {
+    uint32_t b = t * per + k;
+    if (b < cnt) {
+      const uint32_t c = chist[b];
       cstart[b] = run;
       ccur[b] = run;
-      run += chist[b];
+      run += c;
+      ts[b] = trun;
+      tile_start[b] = trun;
+      trun += fine_tiles(c);
     }
+  }
+  const uint32_t ntiles = tpart[1023];
+  if (t == 0) {
+    ts[cnt] = ntiles;
+    tile_start[cnt] = ntiles;
+  }
+  __syncthreads();
+  // tile -> bin: the bin whose first tile is the last one <= tile
+  for (uint32_t tile = t; tile < ntiles && tile < max_tiles; tile += 1024) {
+    uint32_t lo = 0, hi = cnt - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (ts[mid] <= tile) lo = mid; else hi = mid - 1;
+    }
+    tile_bin[tile] = lo;
   }
 }
 
@@ -270,37 +306,105 @@ __global__ void __launch_bounds__(1024) k_scatter_coarse(const uint32_t* __restr
     }
 }
 
-// One workgroup per (window, coarse bin): counting sort by the low bucket bits in LDS.  Writes, for each of the
-// bin's FINE buckets, hist (count) and offs (start in `sorted`), and the entries (index | sign) grouped by bucket.
-__global__ void __launch_bounds__(256) k_sort_fine(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ cstart,
-                                                  const uint32_t* __restrict__ chist, MsmPlan pl, int nbin,
-                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
-                                                  uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t cnt[FINE], cur[FINE];
-  const int k = blockIdx.x, w = k / nbin, b = k % nbin;
-  const uint32_t s0 = cstart[k], s1 = s0 + chist[k];
+// Ranks for a counting sort through LDS counters: returns the counter's value before this lane's increment.  When a
+// crowd of the wave's lanes meets on one counter (structured scalars: every entry of a tile in the same bucket) the
+// crowd shares ONE atomic and ranks itself by ballot; lanes outside a crowd take their own atomic (the uniform case:
+// one ballot and a compare of overhead).
+__device__ __forceinline__ uint32_t lds_rank(uint32_t* cnt, uint32_t key, bool valid) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t todo = __ballot(valid);
+  uint32_t r = 0;
+  for (int it = 0; it < 4 && todo; it++) {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
+    const bool same = ((todo >> lane) & 1ull) && key == k0;
+    const uint64_t sm = __ballot(same);
+    if (__popcll(sm) < 4) break;
+    uint32_t base = 0;
+    if (lane == (uint32_t)leader) base = atomicAdd(&cnt[k0], (uint32_t)__popcll(sm));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (same) r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+    todo &= ~sm;
+  }
+  if ((todo >> lane) & 1ull) r = atomicAdd(&cnt[key], 1u);
+  return r;
+}
+
+// Fine sort, step 1.  One workgroup per TILE of a (window, coarse bin): histogram of the tile's low bucket bits in LDS,
+// then one global atomic per non-empty bucket adds it to hist (the bucket's final population, which the accumulation
+// reads) and returns the tile's first rank inside that bucket (tbase).  A bin of one tile gets rank 0 everywhere.
+__global__ void __launch_bounds__(256) k_fine_count(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ cstart,
+                                                   const uint32_t* __restrict__ chist, const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ tile_bin, uint32_t ncnt, MsmPlan pl, int nbin,
+                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ tbase) {
+  __shared__ uint32_t cnt[FINE];
+  const uint32_t tile = blockIdx.x;
+  if (tile >= tile_start[ncnt]) return;
+  const uint32_t k = tile_bin[tile], w = k / (uint32_t)nbin, b = k % (uint32_t)nbin;
+  const uint32_t s0 = cstart[k] + (tile - tile_start[k]) * FINE_TILE, end = cstart[k] + chist[k];
+  const uint32_t s1 = s0 + FINE_TILE < end ? s0 + FINE_TILE : end;
   if (threadIdx.x < FINE) cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t p = s0 + threadIdx.x; p < s1; p += 256) atomicAdd(&cnt[(coarse[p] >> 24) & (FINE - 1)], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = s0;
-    for (int q = 0; q < FINE; q++) {
-      cur[q] = run;
-      run += cnt[q];
-    }
+  for (uint32_t p0 = s0; p0 < s1; p0 += 256) {
+    const uint32_t p = p0 + threadIdx.x;
+    const bool valid = p < s1;
+    const uint32_t key = valid ? (coarse[p] >> 24) & (FINE - 1) : 0u;
+    (void)lds_rank(cnt, key, valid);
   }
   __syncthreads();
   if (threadIdx.x < FINE) {
+    const uint32_t c = cnt[threadIdx.x];
     const size_t bid = (size_t)w * pl.nb + (size_t)b * FINE + threadIdx.x;
-    hist[bid] = cnt[threadIdx.x];
-    offs[bid] = cur[threadIdx.x];
+    tbase[(size_t)tile * FINE + threadIdx.x] = c ? atomicAdd(&hist[bid], c) : 0u;
+  }
+}
+
+// Fine sort, step 2.  Every tile scans its bin's bucket populations (hist is complete: the kernel boundary) into bucket
+// starts - the bin's first tile also stores them to offs - and places its entries (index | sign) at
+// start(bucket) + tbase(tile, bucket) + rank inside the tile.
+__global__ void __launch_bounds__(256) k_fine_place(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ cstart,
+                                                   const uint32_t* __restrict__ chist, const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ tile_bin, uint32_t ncnt, MsmPlan pl, int nbin,
+                                                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tbase,
+                                                   uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t start[FINE], cur[FINE], wtot[2];
+  const uint32_t tile = blockIdx.x;
+  if (tile >= tile_start[ncnt]) return;
+  const uint32_t k = tile_bin[tile], w = k / (uint32_t)nbin, b = k % (uint32_t)nbin;
+  const uint32_t first = cstart[k], end = first + chist[k];
+  const uint32_t s0 = first + (tile - tile_start[k]) * FINE_TILE;
+  const uint32_t s1 = s0 + FINE_TILE < end ? s0 + FINE_TILE : end;
+  const size_t bid0 = (size_t)w * pl.nb + (size_t)b * FINE;
+  if (threadIdx.x < FINE) {  // exclusive scan of the 128 populations by the first two waves
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t c = hist[bid0 + threadIdx.x];
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+      if ((int)lane >= d) incl += v;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    start[threadIdx.x] = incl - c;
   }
   __syncthreads();
-  for (uint32_t p = s0 + threadIdx.x; p < s1; p += 256) {
-    const uint32_t v = coarse[p];
-    const uint32_t pos = atomicAdd(&cur[(v >> 24) & (FINE - 1)], 1u);
-    if (pos < s1) sorted[pos] = (v & 0x00FFFFFFu) | (v & MSM_NEG);
+  if (threadIdx.x < FINE) {
+    const uint32_t st = first + start[threadIdx.x] + (threadIdx.x >= 64 ? wtot[0] : 0u);
+    start[threadIdx.x] = st + tbase[(size_t)tile * FINE + threadIdx.x];
+    cur[threadIdx.x] = 0;
+    if (tile == tile_start[k]) offs[bid0 + threadIdx.x] = st;
+  }
+  __syncthreads();
+  for (uint32_t p0 = s0; p0 < s1; p0 += 256) {
+    const uint32_t p = p0 + threadIdx.x;
+    const bool valid = p < s1;
+    const uint32_t v = valid ? coarse[p] : 0u;
+    const uint32_t key = (v >> 24) & (FINE - 1);
+    const uint32_t rk = lds_rank(cur, key, valid);
+    if (valid) {
+      const uint32_t pos = start[key] + rk;
+      if (pos < end) sorted[pos] = (v & 0x00FFFFFFu) | (v & MSM_NEG);
+    }
   }
 }
 
@@ -714,9 +818,13 @@ __global__ void __launch_bounds__(256) k_bucket_sum(const xyzz* __restrict__ bt,
 template <class LoadW>
 __device__ __forceinline__ void window_combine_store(const MsmPlan& pl, LoadW load, uint8_t* out_affine, xyzz* out_xyzz) {
   const uint32_t lane = threadIdx.x & 3u;
-  fe29 P = quad_spread(xyzz29_from(load(pl.W - 1)), lane);
+  // windows above the scalars' top set bit are empty (64-bit scalars fill 5 of 9, {0,1} scalars one): O doubled stays
+  // O, so the chain starts at the highest window that holds something
+  int top = pl.W - 1;
+  while (top > 0 && xyzz_is_inf(load(top))) top--;
+  fe29 P = quad_spread(xyzz29_from(load(top)), lane);
 #pragma unroll 1
-  for (int w = pl.W - 2; w >= 0; w--) {
+  for (int w = top - 1; w >= 0; w--) {
 #pragma unroll 1
     for (int i = 0; i < pl.c; i++) P = quad_dbl(P, lane);
     P = quad_spread(xyzz29_add(quad_gather(P), xyzz29_from(load(w))), lane);
@@ -937,6 +1045,9 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
 
   // workspace layout (sizes computed with a null base first)
   uint32_t *codes, *ranks, *sorted, *hist, *offs, *cursor, *order, *bins, *heavy_off, *chist, *cstart, *ccur;
+  uint32_t *tile_start, *tile_bin, *tbase;
+  // tiles of the fine sort: one per non-empty (window, bin) plus one per FINE_TILE entries
+  const size_t max_tiles = (size_t)pl.W * ((size_t)pl.nb >> FINE_BITS) + wn / FINE_TILE + 1;
   xyzz *partial, *buckets, *segv, *wsum;
   auto carve = [&](void* base) {
     Carver cv(base);
@@ -946,6 +1057,9 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     size_t zero_end = cv.off;
     cstart = cv.take<uint32_t>(CO_MAXCNT);
     ccur = cv.take<uint32_t>(CO_MAXCNT);
+    tile_start = cv.take<uint32_t>(CO_MAXCNT + 1);
+    tile_bin = cv.take<uint32_t>(max_tiles);
+    tbase = cv.take<uint32_t>(max_tiles * FINE);
     codes = cv.take<uint32_t>(wn);
     ranks = cv.take<uint32_t>(wn);
     sorted = cv.take<uint32_t>(wn);
@@ -1011,10 +1125,17 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
                        ranks, hist);
   if (two_level) {
     // windows [0, wc): coarse partition by the high bucket bits, then one workgroup per coarse bin sorts it in LDS
-    hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, chist, (uint32_t)(wc * nbin), cstart, ccur);
+    const uint32_t ncnt = (uint32_t)(wc * nbin);
+    // tiles that can exist: every non-empty bin rounds up once, on top of (entries of the windows) / FINE_TILE
+    const uint32_t tile_grid = (uint32_t)(ncnt + ((size_t)wc * ne) / FINE_TILE);
+    hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, chist, ncnt, cstart, ccur, tile_start, tile_bin,
+                       (uint32_t)max_tiles);
     hipLaunchKernelGGL(k_scatter_coarse, dim3((ne32 + CO_TILE - 1) / CO_TILE), dim3(1024), 0, st, codes, ne32, pl, wc, nbin,
                        ccur, ranks /* coarse entries */);
-    hipLaunchKernelGGL(k_sort_fine, dim3(wc * nbin), dim3(256), 0, st, ranks, cstart, chist, pl, nbin, hist, offs, sorted);
+    hipLaunchKernelGGL(k_fine_count, dim3(tile_grid), dim3(256), 0, st, ranks, cstart, chist, tile_start, tile_bin, ncnt, pl,
+                       nbin, hist, tbase);
+    hipLaunchKernelGGL(k_fine_place, dim3(tile_grid), dim3(256), 0, st, ranks, cstart, chist, tile_start, tile_bin, ncnt, pl,
+                       nbin, hist, tbase, offs, sorted);
     if (wc < pl.W) {  // the narrow top window: ranks from k_rank_top, one scan and scatter for it alone
       hipLaunchKernelGGL(k_scan, dim3(pl.W - wc), dim3(1024), 0, st, hist, ne32, pl, wc, offs, cursor);
       hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W - wc), dim3(256), 0, st, codes, ranks, ne32, pl, wc, offs,
