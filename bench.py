@@ -93,7 +93,25 @@ def cpu_baseline(sc, pts, n_bits, sample, gpu_verdicts):
         raise SystemExit("PARITY FAILURE: GPU verdicts differ from the CPU restatement on the sample")
     res = dict(value=sample / dt, unit="verifies/s", cores=1, kind="port",
                sample="first %d proofs of the same batch, oracle/bp_ref.c (C restatement of the reference's "
-                      "algorithm; GHC is not available), verdicts identical to the GPU's" % sample)
+                      "algorithm; GHC is not available), verdicts identical to the GPU's" % sample,
+               algorithm="the reference's operation sequence with every `mul` in JACOBIAN coordinates (one inversion "
+                         "per product) on 4x64-bit limbs: faster than the reference's own affine ladder on GMP "
+                         "Integers, i.e. this baseline flatters the CPU; see affine_ladder for the literal form")
+    # the LITERAL algorithm of `mul` on a `PA`: affine double-and-add, one field inversion per doubling / addition
+    lit = max(4, sample // 12)
+    out2 = ctypes.create_string_buffer(lit)
+    L.bpref_set_mul_mode(1)
+    t0 = time.perf_counter()
+    L.bpref_verify_batch(n_bits, 1, ctypes.c_size_t(B), sc.ctypes.data_as(ctypes.c_char_p),
+                         pts.ctypes.data_as(ctypes.c_char_p), ctypes.c_size_t(0), ctypes.c_size_t(lit), out2)
+    dta = time.perf_counter() - t0
+    L.bpref_set_mul_mode(0)
+    if not (np.frombuffer(out2.raw, dtype=np.uint8) == gpu_verdicts[:lit]).all():
+        raise SystemExit("PARITY FAILURE: GPU verdicts differ from the affine-ladder CPU restatement")
+    res["affine_ladder"] = dict(value=lit / dta, unit="verifies/s", cores=1, kind="port",
+                                sample="first %d proofs, the same C restatement with `mul` as the literal affine "
+                                       "double-and-add of Data.Curve.Weierstrass (an inversion per step, binary "
+                                       "extended Euclid)" % lit)
     # the same port over the box's CPU share (independent proofs, one slice per thread; the reference itself is
     # single-threaded): a second, short figure next to the one-core baseline
     cores = min(16, os.cpu_count() or 1)
@@ -144,6 +162,34 @@ def msm_algorithmic_mads(n_local, direct_max=0):
     return mm * MADS_PER_MODMUL, dict(path="bucket", c=c, windows=W, glv=True)
 
 
+def msm_cpu_baseline(es, pts, got):
+    """`sumExps` on one host core (oracle/bp_ref.c, Utils.hs:76-80 as written: one double-and-add product per term,
+    pairwise sums) over the first 2^12 / 2^9 terms of the same scalars and points, Jacobian and literal affine `mul`;
+    `got(n)` returns the engine's result for the same prefix, which must be the same point."""
+    so = os.path.join(ROOT, "oracle", "libbp_ref.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    L = ctypes.CDLL(so)
+    out = ctypes.create_string_buffer(64)
+    res = {}
+    for mode, n, key in ((0, 4096, "jacobian"), (1, 512, "affine_ladder")):
+        n = min(n, len(es))
+        L.bpref_set_mul_mode(mode)
+        t0 = time.perf_counter()
+        L.bpref_sum_exps(es[:n].ctypes.data_as(ctypes.c_char_p), pts[:n * 64].ctypes.data_as(ctypes.c_char_p),
+                         ctypes.c_size_t(n), out)
+        dt = time.perf_counter() - t0
+        L.bpref_set_mul_mode(0)
+        if out.raw != got(n):
+            raise SystemExit("PARITY FAILURE: MSM of the first %d terms differs from the CPU restatement" % n)
+        res[key] = dict(value=n / dt, unit="points/s", cores=1, kind="port",
+                        sample="sumExps over the first %d terms of the 2^k-point workload, result equal to the GPU's" % n)
+    base = dict(res["jacobian"])
+    base["algorithm"] = "the reference's sumExps order with Jacobian products (flatters the CPU); affine_ladder = literal"
+    base["affine_ladder"] = res["affine_ladder"]
+    return base
+
+
 def make_points(eng, n, seed):
     """n points k_i * G with seeded k_i (cheap derivation, points uploaded once)."""
     rng = np.random.default_rng(seed)
@@ -167,7 +213,7 @@ def make_scalars(kind, n, seed):
     return es
 
 
-def msm_bench(eng, rank, world, dist, logns, iters):
+def msm_bench(eng, rank, world, dist, logns, iters, cpu=True):
     """MSM points/s for N = 2^logn total points sharded over the ranks by contiguous ranges (each shard resident in
     its GPU's HBM), scalars uniform / 64-bit / {0,1}.  `points_per_s` INCLUDES the upload of the scalars from pinned
     host memory every iteration and EXCLUDES the one-time point upload; the resident-scalar
@@ -219,6 +265,12 @@ def msm_bench(eng, rank, world, dist, logns, iters):
                 if got != exp:
                     raise SystemExit("PARITY FAILURE: MSM result differs from (sum e_i k_i) * G at N = 2^%d" % logn)
                 row["checked"] = "result == (sum e_i k_i mod r) * G"
+            if kind == "uniform" and logn == max(logns) and world == 1 and cpu:
+                def got(m):
+                    eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), m, d_out.data_ptr())
+                    eng.sync()
+                    return bytes(d_out.cpu().numpy())
+                row["cpu_baseline"] = msm_cpu_baseline(es, pts_all, got)
             barrier()
             t0 = time.perf_counter()
             for _ in range(iters):
@@ -302,7 +354,9 @@ def main():
                     help="auto = weak (the headline); the split of BASELINE config 4 is then reported as strong_split")
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=0)
-    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="transcript-hashing threads per rank (0 = min(16, usable cores / ranks on this host))")
+    ap.add_argument("--pin", type=int, default=1, help="with several ranks on a host: restrict each rank to its own cores")
     ap.add_argument("--cpu-sample", type=int, default=192, help="proofs of the batch timed on the CPU restatement (~16 s on one core)")
     ap.add_argument("--msm-logn", type=int, default=20, help="largest MSM size 2^k of the config-3 leg (0 = skip)")
     ap.add_argument("--msm-min-logn", type=int, default=16)
@@ -315,6 +369,10 @@ def main():
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (a.gpus, world, a.gpus))
+    # host budget of this rank: the usable cores divided by the ranks on this host; optionally pinned to its own slice
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pinned = bpdist.pin_rank_cpus(local_rank, local_world) if (a.pin and local_world > 1) else None
+    host_threads = a.host_threads or int(os.environ.get("BP_HOST_THREADS", "0")) or bpdist.host_thread_budget(local_world)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -337,13 +395,13 @@ def main():
     else:
         B, total = a.batch, a.batch * world
     k = n_bits.bit_length() - 1
-    gen_threads = min(16, os.cpu_count() or 1)
+    gen_threads = host_threads
     inputs = proofgen.random_inputs(4 + 1000 * rank, n_bits, B)  # seed 4
     t0 = time.perf_counter()
     sc, pts = proofgen.make_proofs(eng, _lib.enc_point(h), n_bits, B, inputs, threads=gen_threads)
     gen_s = time.perf_counter() - t0
     expected = corrupt(sc, pts, k, np.random.default_rng(40 + rank))
-    job = eng.vjob(n_bits, 1, B, a.chunks, a.host_threads)
+    job = eng.vjob(n_bits, 1, B, a.chunks, host_threads)
     job.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
 
     def check(v):
@@ -371,7 +429,7 @@ def main():
     iso = None
     api = None
     if rank == 0:
-        job1 = eng.vjob(n_bits, 1, B, 1, a.host_threads)
+        job1 = eng.vjob(n_bits, 1, B, 1, host_threads)
         job1.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
         check(job1.run())
         eng.profile(True)
@@ -412,15 +470,14 @@ def main():
     # BASELINE config 4 as literally stated - the job's 65,536 proofs SPLIT over the GPUs - next to a weak headline
     strong = None
     if world > 1 and scaling == "weak":
-        lo, hi = bpdist.shard_range(a.batch, rank, world)
-        Bs = hi - lo
-        js = eng.vjob(n_bits, 1, Bs, a.chunks, a.host_threads)
-        scs, pts_s = np.ascontiguousarray(sc[:, :Bs]), np.ascontiguousarray(pts[:, :Bs])
-        # the wrong-V corruption points at the neighbouring proof's V, which the slice keeps except for its last proof
-        exp_s = expected[:Bs].copy()
+        # each rank takes its share from the front of its own batch (bpdist.strong_split_slice; the 2-rank gloo test
+        # checks the rule that a proof carrying its neighbour's V stays wrong inside a slice)
+        scs, pts_s, exp_s = bpdist.strong_split_slice(sc, pts, expected, a.batch, rank, world)
+        Bs = len(exp_s)
+        js = eng.vjob(n_bits, 1, Bs, a.chunks, host_threads)
         js.load(scs.ctypes.data_as(ctypes.c_char_p), pts_s.ctypes.data_as(ctypes.c_char_p))
         first = np.frombuffer(js.run(), dtype=np.uint8)
-        if not (first[:Bs - 1] == exp_s[:Bs - 1]).all():
+        if not (first == exp_s).all():
             raise SystemExit("rank %d: strong-split verdicts differ from the expected ones" % rank)
         barrier()
         t0 = time.perf_counter()
@@ -440,7 +497,7 @@ def main():
     msm = None
     if a.msm_logn > 0:
         logns = list(range(min(a.msm_min_logn, a.msm_logn), a.msm_logn + 1))
-        msm = msm_bench(eng, rank, world, dist, logns, 5)
+        msm = msm_bench(eng, rank, world, dist, logns, 5, cpu=a.cpu_sample > 0)
 
     if rank == 0:
         value = total * a.steps / dt
@@ -465,8 +522,8 @@ def main():
                             % (total, n_bits, " split over %d GPUs" % world if scaling == "strong" and world > 1 else
                                (" per GPU x %d GPUs" % world if world > 1 else "")),
                 "proofs_total": total, "proofs_per_gpu": B, "bits": n_bits, "m": 1,
-                "host_threads": a.host_threads or int(os.environ.get("BP_HOST_THREADS", "0")) or
-                min(16, os.cpu_count() or 1),
+                "host_threads": host_threads, "usable_cores": bpdist.usable_cores(), "ranks_on_host": local_world,
+                "pinned_cores": len(pinned) if pinned else None,
                 "chunks": a.chunks or (4 if B >= 16384 else (2 if B >= 4096 else 1)),
                 "proofgen_s": gen_s,
                 "hw_queues_env": hwq, "stream_pool": pool, "concurrent_streams": conc,
@@ -507,6 +564,8 @@ def main():
                 "metric": "MSM points/sec (secp256k1, BASELINE.json configs[2])",
                 "n": top["n"], "points_per_s": top["uniform"]["points_per_s"], "ms": top["uniform"]["ms"],
                 "frac": top["uniform"]["frac"],
+                "cpu_baseline": top.get("cpu_baseline"),
+                "structured": {k2: dict(ms=top[k2]["ms"], points_per_s=top[k2]["points_per_s"]) for k2 in ("64bit", "01")},
                 "resident_points_per_s": top["uniform"].get("resident_points_per_s"),
                 "prepared_points_per_s": top["uniform"].get("prepared_points_per_s"),
                 "prepared_frac": top["uniform"].get("prepared_frac"),

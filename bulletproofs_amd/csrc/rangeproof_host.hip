@@ -7,6 +7,7 @@
 // GHC exists in this image).  Hashing is multi-threaded over independent proofs
 // and ping-pongs with the GPU: the batch is cut into chunks, and while the GPU
 // runs one chunk's round the host hashes the other chunk's transcript.
+#include <sched.h>
 #include <stdio.h>
 #include <atomic>
 #include <chrono>
@@ -100,12 +101,25 @@ class Pool {
   std::atomic<size_t> next_{0};
 };
 
+// Hashing threads of a job when the caller names none: BP_HOST_THREADS, else the cores this process may run on (its
+// affinity mask: the box's CPU share, not the machine's core count) divided by the ranks that share the host
+// (BP_LOCAL_RANKS, else torchrun's LOCAL_WORLD_SIZE), at most 16 (a 65,536-proof step fits 18 ms + 114 ms / threads).
+// Eight ranks on one node therefore do not start 8 x 16 threads.
 int default_threads() {
   const char* e = getenv("BP_HOST_THREADS");
   if (e && atoi(e) > 0) return atoi(e);
-  unsigned hc = std::thread::hardware_concurrency();
-  if (hc == 0) hc = 1;
-  return (int)(hc > 16 ? 16 : hc);
+  int cores = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+  if (cores <= 0) cores = (int)std::thread::hardware_concurrency();
+  if (cores <= 0) cores = 1;
+  int ranks = 1;
+  const char* lr = getenv("BP_LOCAL_RANKS");
+  if (!lr) lr = getenv("LOCAL_WORLD_SIZE");
+  if (lr && atoi(lr) > 0) ranks = atoi(lr);
+  int t = cores / ranks;
+  if (t < 1) t = 1;
+  return t > 16 ? 16 : t;
 }
 
 struct Chunk {

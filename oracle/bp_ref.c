@@ -182,9 +182,70 @@ static jac jac_add_affine(const jac* p, const pt* q) {
   r.Z = FQ_MUL(&p->Z, &H);
   return r;
 }
+/* a^-1 mod m by the binary extended Euclid (HAC 14.61 for an odd modulus), as a bignum library's modular inverse
+ * would (galois-field's `recip` on a prime field goes through GMP, not through a^(m-2)); 0 for a = 0 */
+static void shr1(fe* a, uint64_t top) {
+  a->v[0] = (a->v[0] >> 1) | (a->v[1] << 63);
+  a->v[1] = (a->v[1] >> 1) | (a->v[2] << 63);
+  a->v[2] = (a->v[2] >> 1) | (a->v[3] << 63);
+  a->v[3] = (a->v[3] >> 1) | (top << 63);
+}
+static void halve_mod(fe* x, const fe* m) {
+  uint64_t top = 0;
+  if (x->v[0] & 1) { fe t; top = fe_add_raw(&t, x, m); *x = t; }
+  shr1(x, top);
+}
+static fe mod_inv_euclid(const fe* a, const fe* m) {
+  fe u = *a, v = *m, x1 = fe_from_u64(1), x2 = fe_from_u64(0), one = fe_from_u64(1), t;
+  if (fe_is_zero(a)) return x2;
+  while (fe_cmp(&u, &one) != 0 && fe_cmp(&v, &one) != 0) {
+    while (!(u.v[0] & 1)) { shr1(&u, 0); halve_mod(&x1, m); }
+    while (!(v.v[0] & 1)) { shr1(&v, 0); halve_mod(&x2, m); }
+    if (fe_cmp(&u, &v) >= 0) { fe_sub_raw(&t, &u, &v); u = t; x1 = mod_sub(&x1, &x2, m); }
+    else { fe_sub_raw(&t, &v, &u); v = t; x2 = mod_sub(&x2, &x1, m); }
+  }
+  return fe_cmp(&u, &one) == 0 ? x1 : x2;
+}
+/* `<>` on affine points with the library-style inverse: the step of the literal affine ladder below */
+static pt pt_add_affine_lit(const pt* a, const pt* b) {
+  if (a->inf) return *b;
+  if (b->inf) return *a;
+  fe lam;
+  if (fe_cmp(&a->x, &b->x) == 0) {
+    fe s = FQ_ADD(&a->y, &b->y);
+    if (fe_is_zero(&s)) return pt_inf();
+    fe xx = FQ_MUL(&a->x, &a->x), three = fe_from_u64(3), num = FQ_MUL(&xx, &three);
+    fe den = FQ_ADD(&a->y, &a->y), di = mod_inv_euclid(&den, &FP);
+    lam = FQ_MUL(&num, &di);
+  } else {
+    fe num = FQ_SUB(&b->y, &a->y), den = FQ_SUB(&b->x, &a->x), di = mod_inv_euclid(&den, &FP);
+    lam = FQ_MUL(&num, &di);
+  }
+  pt r;
+  r.inf = 0;
+  fe l2 = FQ_MUL(&lam, &lam), t = FQ_SUB(&l2, &a->x);
+  r.x = FQ_SUB(&t, &b->x);
+  fe d = FQ_SUB(&a->x, &r.x), ld = FQ_MUL(&lam, &d);
+  r.y = FQ_SUB(&ld, &a->y);
+  return r;
+}
+/* 0: products in Jacobian coordinates with one inversion at the end (generous to the reference);
+ * 1: the LITERAL affine double-and-add that `mul` on a `PA` performs (Data.Curve.Weierstrass affine `dbl` / `add`:
+ *    one field inversion per doubling and per addition).  Same group elements either way. */
+static int g_mul_mode = 0;
+void bpref_set_mul_mode(int mode) { g_mul_mode = mode ? 1 : 0; }
+
 /* `mul`: k * P by double-and-add, k canonical (< r) */
 static pt pt_mul(const pt* p, const fe* k) {
   if (p->inf || fe_is_zero(k)) return pt_inf();
+  if (g_mul_mode == 1) {
+    pt acc = pt_inf();
+    for (int i = 255; i >= 0; i--) {
+      if (!acc.inf) acc = pt_add_affine_lit(&acc, &acc);
+      if ((k->v[i >> 6] >> (i & 63)) & 1) acc = pt_add_affine_lit(&acc, p);
+    }
+    return acc;
+  }
   jac acc;
   memset(&acc, 0, sizeof acc);
   acc.Y = fe_from_u64(1);

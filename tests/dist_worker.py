@@ -17,7 +17,24 @@ from bulletproofs_amd import _lib, dist as bpdist  # noqa: E402
 
 
 class OracleEngine:
-    """Same byte-level surface as bulletproofs_amd.Engine for the calls dist.py makes."""
+    """Same byte-level surface as bulletproofs_amd.Engine for the calls dist.py makes.  The `_dev` calls take raw
+    addresses like the real engine's; here they are addresses of CPU tensors (gloo), read and written with ctypes."""
+
+    def msm_dev(self, p_scalars, p_points, n, p_out, window_bits=0):
+        import ctypes
+        sc = ctypes.string_at(p_scalars, 32 * n)
+        pt = ctypes.string_at(p_points, 64 * n)
+        ctypes.memmove(p_out, self.msm_raw(sc, pt, n), 64)
+
+    def point_sum_dev(self, p_points, n, p_out):
+        import ctypes
+        acc = o.O
+        for q in _lib.dec_points(ctypes.string_at(p_points, 64 * n), n):
+            acc = o.point_add(acc, q)
+        ctypes.memmove(p_out, _lib.enc_point(acc), 64)
+
+    def sync(self):
+        pass
 
     def msm_raw(self, scalars, points, n):
         return _lib.enc_point(o.sum_exps(_lib.dec_scalars(scalars, n), _lib.dec_points(points, n)))
@@ -61,15 +78,26 @@ def main():
     got = _lib.dec_point(bpdist.sharded_msm(eng, _lib.enc_scalars(es), _lib.enc_points(ps), n))
     assert got == o.sum_exps(es, ps), "sharded MSM mismatch on rank %d" % rank
     assert bpdist.shard_range(11, 0, 2) == (0, 6) and bpdist.shard_range(11, 1, 2) == (6, 11)
-    if real:  # the device-resident form: shards stay in HBM, partial sums are all-gathered on the device
-        import torch
-        lo, hi = bpdist.shard_range(n, rank, world)
-        d_s = torch.frombuffer(bytearray(_lib.enc_scalars(es[lo:hi])), dtype=torch.uint8).cuda()
-        d_p = torch.frombuffer(bytearray(_lib.enc_points(ps[lo:hi])), dtype=torch.uint8).cuda()
-        d_o = torch.zeros(64, dtype=torch.uint8, device="cuda")
-        bpdist.sharded_msm_dev(eng, d_s, d_p, hi - lo, d_o)
+    # the resident form: every rank's shard stays where it is (HBM under nccl, CPU tensors under gloo), the 64-byte
+    # partial sums are all-gathered into one tensor and summed by ONE engine call - with two gloo ranks this runs the
+    # world > 1 branch of sharded_msm_dev, gather_and_sum_dev included
+    import torch
+    dev = "cuda" if real else "cpu"
+    lo, hi = bpdist.shard_range(n, rank, world)
+    d_s = torch.frombuffer(bytearray(_lib.enc_scalars(es[lo:hi])), dtype=torch.uint8).to(dev)
+    d_p = torch.frombuffer(bytearray(_lib.enc_points(ps[lo:hi])), dtype=torch.uint8).to(dev)
+    d_o = torch.zeros(64, dtype=torch.uint8, device=dev)
+    bpdist.sharded_msm_dev(eng, d_s, d_p, hi - lo, d_o)
+    eng.sync()
+    assert _lib.dec_point(bytes(d_o.cpu().numpy())) == o.sum_exps(es, ps), "resident sharded MSM mismatch"
+    if real:
+        # the gather-and-sum step alone on a FAKE [4, 64] gathered tensor (this pool has one GPU per box): what four
+        # ranks' partial sums would look like, incl. O and a cancelling pair, through bp_point_sum_dev
+        fake = [ps[0], o.O, ps[1], o.point_neg(ps[0])]
+        gathered = torch.frombuffer(bytearray(_lib.enc_points(fake)), dtype=torch.uint8).cuda().reshape(4, 64)
+        eng.point_sum_dev(gathered.data_ptr(), 4, d_o.data_ptr())
         eng.sync()
-        assert _lib.dec_point(bytes(d_o.cpu().numpy())) == o.sum_exps(es, ps), "device-resident sharded MSM mismatch"
+        assert _lib.dec_point(bytes(d_o.cpu().numpy())) == ps[1], "bp_point_sum_dev over a gathered tensor"
         # bp_point_sum_dev alone: the fold of <> over a list, incl. O and a pair P, -P
         qs = ps[:5] + [o.O, o.point_neg(ps[0])]
         d_q = torch.frombuffer(bytearray(_lib.enc_points(qs)), dtype=torch.uint8).cuda()
@@ -101,6 +129,24 @@ def main():
             pt[r, p] = np.frombuffer(_lib.enc_point(q), dtype=np.uint8)
     v = bpdist.sharded_verify(eng, nb, 1, B, sc, pt)
     assert v.tolist() == [1, 1, 1, 0, 1], "sharded verify mismatch on rank %d: %s" % (rank, v.tolist())
+    # --- bench.py's strong split: the front of each rank's own batch, "wrong V = the neighbour's V" stays wrong ---
+    exp = np.array([1, 1, 1, 0, 1], dtype=np.uint8)
+    vrow = 4 + 2 * k
+    for p in (0, 2):  # bench.corrupt's third kind: proof p carries the V of proof (p + 1) % B
+        pt[vrow, p] = pt[vrow, (p + 1) % B]
+        exp[p] = 0
+    for split in (3, 5):  # a job of `split` proofs over the two ranks: shares (2, 1) and (3, 2)
+        scs, pts_s, exp_s = bpdist.strong_split_slice(sc, pt, exp, split, rank, world)
+        lo, hi = bpdist.shard_range(split, rank, world)
+        assert scs.shape[1] == pts_s.shape[1] == len(exp_s) == hi - lo
+        assert scs.flags["C_CONTIGUOUS"] and pts_s.flags["C_CONTIGUOUS"]
+        got_s = eng.verify_batch(nb, 1, hi - lo, scs.tobytes(), pts_s.tobytes())
+        assert [int(bool(x)) for x in got_s] == exp_s.tolist(), "strong-split verdicts on rank %d" % rank
+    # --- per-rank host budget ---
+    cores = bpdist.usable_cores()
+    assert bpdist.host_thread_budget(1) == max(1, min(16, cores))
+    assert bpdist.host_thread_budget(8) == max(1, min(16, cores // 8))
+    assert sum(bpdist.host_thread_budget(world) for _ in range(world)) <= max(world, cores)
     dist.barrier()
     dist.destroy_process_group()
     if real:

@@ -91,3 +91,25 @@ def test_verify_matches_python_oracle(ref, n, m):
     vcs = [o.commit(v, b) for v, b in vs]
     assert c_verify(ref, n, m, pr, vcs) is True
     assert c_verify(ref, n, m, dict(pr, mu=(pr["mu"] + 1) % o.R), vcs) is False
+
+
+def test_literal_affine_ladder_gives_the_same_points(ref):
+    """bpref_set_mul_mode(1): the literal affine double-and-add of `mul` on a `PA` (one inversion per step) - the
+    slower of the two CPU baselines bench.py reports - yields the same group elements as the Jacobian mode."""
+    rng = random.Random(23)
+    out = ctypes.create_string_buffer(64)
+    try:
+        ref.bpref_set_mul_mode(1)
+        for e in golden()["kG"]:
+            ref.bpref_point_mul(_lib.enc_point(o.GEN), _lib.enc_scalar(ux(e["k"])), out)
+            assert _lib.dec_point(out.raw) == up(e["P"])
+        ps = [o.point_mul(o.GEN, rng.randrange(1, o.R)) for _ in range(5)] + [None]
+        es = [rng.randrange(o.R) for _ in range(4)] + [0, 7]
+        ref.bpref_sum_exps(_lib.enc_scalars(es), _lib.enc_points(ps), ctypes.c_size_t(6), out)
+        assert _lib.dec_point(out.raw) == o.sum_exps(es, ps)
+        p = ps[0]
+        ref.bpref_sum_exps(_lib.enc_scalars([5, o.R - 5, 2, 1]), _lib.enc_points([p, p, p, o.point_add(p, p)]),
+                           ctypes.c_size_t(4), out)     # P - P, then 2P + 2P: the doubling branch of `<>`
+        assert _lib.dec_point(out.raw) == o.point_mul(p, 4)
+    finally:
+        ref.bpref_set_mul_mode(0)

@@ -65,3 +65,38 @@ def test_static_rejects_what_does_not_fit(engine):
     assert got == ref
     ref, got = _both(engine, big_s, big_p, 65536, 0)
     assert got == ref
+
+
+def test_static_calls_allocate_nothing():
+    """The property the entry point exists for.  On a FRESH context (bp_msm_dev never called on it, so its grow-only
+    workspace does not exist and a path that reserved it would have to allocate), 100 calls of growing n over the
+    direct and the bucket plans must leave the device's free memory where it was: hipMemGetInfo is read after every
+    call and must never drop below the figure taken after the first (tiny) call, which absorbs whatever the HIP
+    runtime itself sets up on a kernel's first dispatch.  The results are still checked (against a second context's
+    bp_msm_dev, computed before the measurement starts)."""
+    from bulletproofs_amd import Engine
+    ref_eng = Engine(0)
+    eng = Engine(0)  # fresh: only bp_msm_dev_static will ever run on it
+    try:
+        d_s, d_p = _inputs(ref_eng, 65536, 21)
+        sizes = [64 + (65536 - 64) * i // 99 for i in range(100)]
+        plans = [(n, (0, 9, 13)[i % 3]) for i, n in enumerate(sizes)]
+        outs = torch.zeros((len(plans) + 1, 64), dtype=torch.uint8, device="cuda")
+        refs = torch.zeros((len(plans), 64), dtype=torch.uint8, device="cuda")
+        for i, (n, wb) in enumerate(plans):
+            ref_eng.msm_dev(d_s.data_ptr(), d_p.data_ptr(), n, refs[i].data_ptr(), wb)
+        ref_eng.sync()
+        torch.cuda.synchronize()
+        eng.msm_dev_static(d_s.data_ptr(), d_p.data_ptr(), 32, outs[len(plans)].data_ptr(), 0)
+        eng.sync()
+        free_base = torch.cuda.mem_get_info()[0]
+        lowest = free_base
+        for i, (n, wb) in enumerate(plans):
+            eng.msm_dev_static(d_s.data_ptr(), d_p.data_ptr(), n, outs[i].data_ptr(), wb)
+            eng.sync()
+            lowest = min(lowest, torch.cuda.mem_get_info()[0])
+        assert lowest >= free_base, "free device memory fell by %d bytes during bp_msm_dev_static calls" % (free_base - lowest)
+        assert torch.equal(outs[:len(plans)].cpu(), refs.cpu())
+    finally:
+        eng.close()
+        ref_eng.close()
