@@ -25,8 +25,16 @@
 
 namespace bp {
 
-constexpr int LIGHT_MAX = 254;       // buckets with more entries take the heavy path
+constexpr int LIGHT_MAX = 254;       // buckets with more entries always take the heavy path
 constexpr int NBINS = LIGHT_MAX + 2; // bin 0 = heavy, bin k = population LIGHT_MAX+1-k
+// When the non-empty buckets do not even fill the chip's lanes, a light lane's chain IS the kernel's duration (65,536
+// 64-bit scalars with 14-bit windows: 255 buckets of ~256 entries each walked by one lane, 0.9 ms, beside 32,768 buckets
+// of 8).  k_cls_scan then lowers the heavy threshold (bins[2 NBINS + 1]) until at most HEAVY_EXTRA more buckets are
+// heavy: their entries are spread over a workgroup each.  A launch that fills the chip keeps LIGHT_MAX: the light
+// path does no tree reduction and is the cheaper one per entry.
+constexpr uint32_t LIGHT_FILL = 256u * 4u * 64u * 2u;  // lanes of the chip at two waves per SIMD
+constexpr uint32_t HEAVY_EXTRA = 512;                  // two slice workgroups per CU
+constexpr uint32_t LIGHT_MIN = 24;                     // never send shorter chains to the heavy path
 constexpr int SLICE = 2048;          // entries per heavy slice (one 256-thread workgroup)
 
 // ---- 1. digits + histogram --------------------------------------------------
@@ -505,7 +513,19 @@ __global__ void k_cls_scan(uint32_t* bins) {
       bins[NBINS + k] = run;
       run += bins[k];
     }
-    bins[2 * NBINS] = bins[0];
+    // heavy threshold: buckets are ordered by population (descending), so "cnt > thr" is a prefix of `order`
+    uint32_t nonempty = bins[0], thr = LIGHT_MAX, nheavy = bins[0];
+    for (int pop = 1; pop <= LIGHT_MAX; pop++) nonempty += bins[LIGHT_MAX + 1 - pop];
+    if (nonempty < LIGHT_FILL) {
+      for (int pop = LIGHT_MAX; pop > (int)LIGHT_MIN; pop--) {
+        const uint32_t c = bins[LIGHT_MAX + 1 - pop];
+        if (nheavy + c > bins[0] + HEAVY_EXTRA) break;
+        nheavy += c;
+        thr = (uint32_t)pop - 1;
+      }
+    }
+    bins[2 * NBINS] = nheavy;
+    bins[2 * NBINS + 1] = thr;
   }
 }
 __global__ void __launch_bounds__(1024) k_cls_scatter(const uint32_t* __restrict__ hist, uint32_t total,
@@ -533,12 +553,12 @@ __global__ void __launch_bounds__(1024) k_cls_scatter(const uint32_t* __restrict
 __device__ __forceinline__ void light_lane(uint32_t t, const uint8_t* __restrict__ points, const uint32_t* __restrict__ hist,
                                            const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
                                            const uint32_t* __restrict__ order, uint32_t total, uint32_t glv, uint32_t nb,
-                                           size_t shift_stride, xyzz* __restrict__ buckets) {
+                                           size_t shift_stride, uint32_t light_max, xyzz* __restrict__ buckets) {
   if (t >= total) return;
   uint32_t bid = order[t];
   uint32_t cnt = hist[bid];
   points += (size_t)(bid / nb) * shift_stride;
-  if (cnt > (uint32_t)LIGHT_MAX) return;  // heavy path owns it
+  if (cnt > light_max) return;  // heavy path owns it
   // the bucket's sum on nine 29-bit limbs (fq29.h): started from the first point, one lazy mixed addition per further
   // point; input points may be O, which the lazy formula does not take
   xyzz29 acc = xyzz29_inf();
@@ -643,7 +663,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ 
   __shared__ xyzz lds[4];
   if (blockIdx.x >= heavy_blocks)
     light_lane((blockIdx.x - heavy_blocks) * blockDim.x + threadIdx.x, points, hist, offs, sorted, order, total, glv, nb,
-               shift_stride, buckets);
+               shift_stride, bins[2 * NBINS + 1], buckets);
   else
     heavy_slices(blockIdx.x, heavy_blocks, points, hist, offs, sorted, order, bins, heavy_off, glv, nb, shift_stride, partial,
                  lds);
@@ -1040,7 +1060,7 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     return BP_ERR_ARG;
   }
   size_t nbt = (size_t)pl.W * pl.nb;
-  size_t max_heavy = wn / (LIGHT_MAX + 1) + 1;
+  size_t max_heavy = wn / (LIGHT_MAX + 1) + 1 + HEAVY_EXTRA;
   size_t max_slices = wn / SLICE + max_heavy + 1;
 
   // workspace layout (sizes computed with a null base first)
