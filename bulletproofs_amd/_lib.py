@@ -57,6 +57,7 @@ SYMBOLS = {
     "bp_point_on_curve": (_int, [_vp, _u8p, _sz, _u8p]),
     "bp_msm": (_int, [_vp, _u8p, _u8p, _sz, _u8p]),
     "bp_msm_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "bp_msm_dev_hs": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "bp_msm_points_create": (_int, [_vp, _u8p, _sz, ctypes.POINTER(_vp)]),
     "bp_msm_points_create_dev": (_int, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
     "bp_msm_points_destroy": (None, [_vp]),
@@ -92,6 +93,8 @@ SYMBOLS = {
     "bp_vjob_destroy": (None, [_vp]),
     "bp_vjob_load": (_int, [_vp, _u8p, _u8p]),
     "bp_vjob_run": (_int, [_vp, _u8p]),
+    "bp_vjob_submit": (_int, [_vp]),
+    "bp_vjob_wait": (_int, [_vp, _u8p]),
     "bp_ipp_prove": (_int, [_vp, ctypes.c_uint32] + [_u8p] * 10),
     "bp_ipp_verify": (_int, [_vp, ctypes.c_uint64, _u8p, ctypes.c_uint32, _u8p, ctypes.c_uint32, _u8p, _u8p, _u8p, _u8p,
                              ctypes.c_uint32, _u8p, _u8p, _u8p]),
@@ -238,6 +241,10 @@ class Engine:
 
     def msm_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
         self._check(self.lib.bp_msm_dev(self.h, d_scalars, d_points, n, window_bits, d_out), "bp_msm_dev")
+
+    def msm_dev_hs(self, h_scalars, d_points, n, d_out, window_bits=0):
+        """bp_msm_dev_hs: scalars at a HOST address (e.g. pinned memory), points and result in device memory."""
+        self._check(self.lib.bp_msm_dev_hs(self.h, h_scalars, d_points, n, window_bits, d_out), "bp_msm_dev_hs")
 
     def msm_points(self, points=None, d_points=None, n=None):
         """bp_msm_points_create(_dev): prepare a fixed point list (bytes, or a device pointer with n) once."""
@@ -613,6 +620,15 @@ class VJob:
     def run(self):
         out = ctypes.create_string_buffer(self.B)
         self.eng._check(self.eng.lib.bp_vjob_run(self.h, out), "bp_vjob_run")
+        return out.raw
+
+    def submit(self):
+        """Start the pass on the job's driver thread (bp_vjob_submit); collect it with wait()."""
+        self.eng._check(self.eng.lib.bp_vjob_submit(self.h), "bp_vjob_submit")
+
+    def wait(self):
+        out = ctypes.create_string_buffer(self.B)
+        self.eng._check(self.eng.lib.bp_vjob_wait(self.h, out), "bp_vjob_wait")
         return out.raw
 
     def close(self):

@@ -134,6 +134,7 @@ void bp_ctx_destroy(bp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->vjob_cache && ctx->vjob_cache_free) ctx->vjob_cache_free(ctx->vjob_cache);
   ctx->vjob_cache = nullptr;
+  bp::msm_host_scalars_release(ctx);
   ctx->msm_ws.release();
   ctx->io.release();
   ctx->gen.release();

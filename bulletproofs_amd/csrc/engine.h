@@ -58,6 +58,11 @@ struct bp_ctx {
   bp::DevBuf gen;       // generator tables (verifier / prover)
   bp::DevBuf vws;       // batch-verifier workspace
   bp::DevBuf pws;       // prover workspace (IPP state, gathered MSM inputs)
+  // bp_msm_dev_hs: staging for scalars uploaded from host memory, its copy stream and per-piece events (lazy)
+  bp::DevBuf msm_stage;
+  hipStream_t msm_copy_stream = nullptr;
+  hipEvent_t msm_copy_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t msm_stage_free = nullptr;
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // generator state (filled by bp_ctx_set_generators); pointers into `gen`
@@ -116,6 +121,10 @@ hipStream_t ctx_chunk_stream(bp_ctx* ctx);
 hipStream_t ctx_aux_stream(bp_ctx* ctx);
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz);
+// the same with the scalars still in (pinned) host memory: uploaded in pieces behind which the bucket work runs
+int msm_run_host_scalars(bp_ctx* ctx, const uint8_t* h_scalars, const void* d_points, size_t n, int c_override,
+                         void* d_out_affine);
+void msm_host_scalars_release(bp_ctx* ctx);
 // The same over the file-scope scratch array of msm.hip instead of ctx->msm_ws (bp_msm_dev_static): calls no
 // hipMalloc / hipFree.  msm_static_init(device) resolves that device's copy of the array once (bp_ctx_create calls it
 // with the device current); msm_static_bytes() is its size.

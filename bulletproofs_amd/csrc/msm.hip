@@ -1010,8 +1010,30 @@ struct MsmPrep {
   int nchunks;
 };
 
+// Scalars that still sit in (pinned) HOST memory (bp_msm_dev_hs): the point range is cut into `parts` contiguous pieces;
+// all pieces' uploads are queued on copy_stream at once, and piece i's digits, bucket sort and bucket accumulation run
+// while piece i + 1 is still crossing PCIe.  Every piece fills its own bucket array (same plan, so the arrays add up
+// index by index); one reduction and one Horner chain follow.
+struct MsmHostScalars {
+  const uint8_t* h_scalars;
+  uint8_t* d_stage;        // n x 32 B
+  hipStream_t copy_stream;
+  hipEvent_t* ev;          // one per part
+  int parts;
+};
+
+// buckets[i] += sum over the other parts' arrays
+__global__ void __launch_bounds__(256) k_add_bucket_arrays(xyzz* __restrict__ buckets, uint32_t count, uint32_t parts) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  xyzz acc = ld_xyzz(&buckets[i]);
+  for (uint32_t p = 1; p < parts; p++) acc = xyzz_add(acc, ld_xyzz(&buckets[(size_t)p * count + i]));
+  st_xyzz(&buckets[i], acc);
+}
+
 static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalars, const void* d_points, size_t n,
-                      int c_override, void* d_out_affine, void* d_out_xyzz, const MsmPrep* prep = nullptr) {
+                      int c_override, void* d_out_affine, void* d_out_xyzz, const MsmPrep* prep = nullptr,
+                      const MsmHostScalars* hs = nullptr) {
   hipStream_t st = ctx->stream;
   const bool profile = ctx->profile && !wsrc.fixed;  // event creation allocates: never on the static path
   void* ws = nullptr;
@@ -1041,7 +1063,7 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     BP_TRY(hipGetLastError());
     return BP_OK;
   };
-  const bool may_direct = !prep && c_override <= 0 && n <= msm_direct_max();
+  const bool may_direct = !prep && !hs && c_override <= 0 && n <= msm_direct_max();
   if (may_direct && n <= msm_single_direct_max()) return run_direct();
   int c = prep ? prep->c : (c_override > 0 ? c_override : msm_choose_c(n));
   if (c < 1 || c > 16) {
@@ -1053,7 +1075,10 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   const size_t shift_stride = prep ? prep->stride : 0;
   if (prep) d_points = prep->d_shifted;
   MsmPlan pl = msm_plan(c, glv ? GLV_BITS : 256);
-  const size_t ne = glv ? 2 * n : n;  // sorted entries per window
+  // pieces of the point range (1 unless the scalars come from the host): `per` terms each, a multiple of 256
+  const uint32_t parts = hs && hs->parts > 1 ? (uint32_t)hs->parts : 1u;
+  const size_t per = parts > 1 ? ((n + parts - 1) / parts + 255) / 256 * 256 : n;
+  const size_t ne = glv ? 2 * per : per;  // sorted entries per window (of one piece)
   size_t wn = (size_t)pl.W * ne;
   if (wn >= (1ull << 32)) {
     ctx->err = "bp_msm: windows * n must be below 2^32";
@@ -1071,9 +1096,9 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   xyzz *partial, *buckets, *segv, *wsum;
   auto carve = [&](void* base) {
     Carver cv(base);
-    hist = cv.take<uint32_t>(nbt);          // zeroed each call
-    bins = cv.take<uint32_t>(2 * NBINS + 8); // zeroed each call (contiguous with hist)
-    chist = cv.take<uint32_t>(CO_MAXCNT);    // zeroed each call: coarse-bin histogram of the two-level sort
+    hist = cv.take<uint32_t>(nbt);          // zeroed for each piece
+    bins = cv.take<uint32_t>(2 * NBINS + 8); // zeroed for each piece (contiguous with hist)
+    chist = cv.take<uint32_t>(CO_MAXCNT);    // zeroed for each piece: coarse-bin histogram of the two-level sort
     size_t zero_end = cv.off;
     cstart = cv.take<uint32_t>(CO_MAXCNT);
     ccur = cv.take<uint32_t>(CO_MAXCNT);
@@ -1088,7 +1113,7 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     order = cv.take<uint32_t>(nbt);
     heavy_off = cv.take<uint32_t>(max_heavy + 1);
     partial = cv.take<xyzz>(max_slices);
-    buckets = cv.take<xyzz>(nbt);
+    buckets = cv.take<xyzz>(nbt * parts);    // one array per piece
     {
       const size_t scan_vals = (size_t)2 * pl.W * (((size_t)pl.nb + 255) / 256);  // k_bucket_scan's bt, tb
       const size_t seg_vals = (size_t)pl.W * pl.nseg;
@@ -1110,92 +1135,112 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
   const int wc = top_narrow ? pl.W - 1 : pl.W;
   const int nbin = pl.nb >> FINE_BITS;
   const bool two_level = glv && !sort_atomic && pl.c > FINE_BITS + 1 && ne < (1u << 24) && wc >= 1 && wc * nbin <= CO_MAXCNT;
-  BP_TRY(hipMemsetAsync(hist, 0, zero_bytes, st));
+  const uint32_t nbt32 = (uint32_t)nbt;
+  const uint32_t fgrid = (uint32_t)(max_heavy < 4096 ? max_heavy : 4096);
 
-  uint32_t n32 = (uint32_t)n, ne32 = (uint32_t)ne, nbt32 = (uint32_t)nbt;
-  if (prep && prep->h_scalars) {
-    // upload and recode chunk by chunk: the copy engine moves chunk i + 1 while the recode kernel digests chunk i
-    const int nch = prep->nchunks < 1 ? 1 : prep->nchunks;
-    const uint32_t per = (uint32_t)(((n + nch - 1) / nch + 255) / 256 * 256);
-    int ci = 0;
-    for (uint32_t i0 = 0; i0 < n32; i0 += per, ci++) {
-      const uint32_t i1 = i0 + per < n32 ? i0 + per : n32;
-      BP_TRY(hipMemcpyAsync(prep->d_stage + (size_t)i0 * 32, prep->h_scalars + (size_t)i0 * 32, (size_t)(i1 - i0) * 32,
-                            hipMemcpyHostToDevice, prep->copy_stream));
-      BP_TRY(hipEventRecord(prep->ev[ci], prep->copy_stream));
-      BP_TRY(hipStreamWaitEvent(st, prep->ev[ci], 0));
-      if (two_level)
-        hipLaunchKernelGGL(k_recode_coarse, dim3((i1 - i0 + CO_SCALARS - 1) / CO_SCALARS), dim3(1024), 0, st,
-                           (const uint8_t*)prep->d_stage, n32, i0, i1, pl, wc, nbin, codes, chist);
-      else
-        hipLaunchKernelGGL(k_recode_glv, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, (const uint8_t*)prep->d_stage, n32, i0,
-                           i1, pl, codes, ranks, hist);
+  if (hs) {  // every piece's upload is queued now; the copy engine runs ahead of the kernels
+    for (uint32_t p = 0; p < parts; p++) {
+      const size_t i0 = (size_t)p * per, i1 = i0 + per < n ? i0 + per : n;
+      if (i0 >= n) break;
+      BP_TRY(hipMemcpyAsync(hs->d_stage + i0 * 32, hs->h_scalars + i0 * 32, (i1 - i0) * 32, hipMemcpyHostToDevice,
+                            hs->copy_stream));
+      BP_TRY(hipEventRecord(hs->ev[p], hs->copy_stream));
     }
-  } else if (two_level)
-    hipLaunchKernelGGL(k_recode_coarse, dim3((n32 + CO_SCALARS - 1) / CO_SCALARS), dim3(1024), 0, st, (const uint8_t*)d_scalars,
-                       n32, 0u, n32, pl, wc, nbin, codes, chist);
-  else if (glv)
-    hipLaunchKernelGGL(k_recode_glv, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, 0u, n32, pl,
-                       codes, ranks, hist);
-  if (glv && GLV_BITS + 1 - pl.c * (pl.W - 1) <= 5)
-    hipLaunchKernelGGL(k_rank_top, dim3((ne32 + 256 * RT_PER - 1) / (256 * RT_PER)), dim3(256), 0, st, ne32, pl, codes, ranks, hist);
-  if (glv) {
-  } else
-    hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint8_t*)d_scalars, n32, pl, codes,
-                       ranks, hist);
-  if (two_level) {
-    // windows [0, wc): coarse partition by the high bucket bits, then one workgroup per coarse bin sorts it in LDS
-    const uint32_t ncnt = (uint32_t)(wc * nbin);
-    // tiles that can exist: every non-empty bin rounds up once, on top of (entries of the windows) / FINE_TILE
-    const uint32_t tile_grid = (uint32_t)(ncnt + ((size_t)wc * ne) / FINE_TILE);
-    hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, chist, ncnt, cstart, ccur, tile_start, tile_bin,
-                       (uint32_t)max_tiles);
-    hipLaunchKernelGGL(k_scatter_coarse, dim3((ne32 + CO_TILE - 1) / CO_TILE), dim3(1024), 0, st, codes, ne32, pl, wc, nbin,
-                       ccur, ranks /* coarse entries */);
-    hipLaunchKernelGGL(k_fine_count, dim3(tile_grid), dim3(256), 0, st, ranks, cstart, chist, tile_start, tile_bin, ncnt, pl,
-                       nbin, hist, tbase);
-    hipLaunchKernelGGL(k_fine_place, dim3(tile_grid), dim3(256), 0, st, ranks, cstart, chist, tile_start, tile_bin, ncnt, pl,
-                       nbin, hist, tbase, offs, sorted);
-    if (wc < pl.W) {  // the narrow top window: ranks from k_rank_top, one scan and scatter for it alone
-      hipLaunchKernelGGL(k_scan, dim3(pl.W - wc), dim3(1024), 0, st, hist, ne32, pl, wc, offs, cursor);
-      hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W - wc), dim3(256), 0, st, codes, ranks, ne32, pl, wc, offs,
-                         sorted);
-    }
-  } else {
-    hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, ne32, pl, 0, offs, cursor);
-    hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W), dim3(256), 0, st, codes, ranks, ne32, pl, 0, offs, sorted);
+    d_scalars = hs->d_stage;
   }
-  hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
-  hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
-  hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
-  if (profile) {  // the previous call's pair has completed on this in-order stream or is read after a sync
-    if (!ctx->msm_ev[0]) {
-      BP_TRY(hipEventCreate(&ctx->msm_ev[0]));
-      BP_TRY(hipEventCreate(&ctx->msm_ev[1]));
-    } else if (ctx->prof_pending_light) {
-      float ms = 0;
-      if (hipEventSynchronize(ctx->msm_ev[1]) == hipSuccess &&
-          hipEventElapsedTime(&ms, ctx->msm_ev[0], ctx->msm_ev[1]) == hipSuccess) {
-        ctx->prof_ms[1] += ms;
-        ctx->prof_calls[1] += 1;
+  uint32_t parts_run = 0;
+  for (uint32_t part = 0; part < parts; part++) {
+    const size_t p0 = (size_t)part * per;
+    if (p0 >= n) break;
+    parts_run++;
+    const uint32_t n32 = (uint32_t)((p0 + per < n ? p0 + per : n) - p0), ne32 = glv ? 2 * n32 : n32;
+    const uint8_t* sc_part = d_scalars ? (const uint8_t*)d_scalars + p0 * 32 : nullptr;
+    const uint8_t* pt_part = prep ? (const uint8_t*)d_points : (const uint8_t*)d_points + p0 * 64;
+    xyzz* bk = buckets + (size_t)part * nbt;
+    if (hs) BP_TRY(hipStreamWaitEvent(st, hs->ev[part], 0));
+    BP_TRY(hipMemsetAsync(hist, 0, zero_bytes, st));
+    if (prep && prep->h_scalars) {
+      // upload and recode chunk by chunk: the copy engine moves chunk i + 1 while the recode kernel digests chunk i
+      const int nch = prep->nchunks < 1 ? 1 : prep->nchunks;
+      const uint32_t cper = (uint32_t)(((n + nch - 1) / nch + 255) / 256 * 256);
+      int ci = 0;
+      for (uint32_t i0 = 0; i0 < n32; i0 += cper, ci++) {
+        const uint32_t i1 = i0 + cper < n32 ? i0 + cper : n32;
+        BP_TRY(hipMemcpyAsync(prep->d_stage + (size_t)i0 * 32, prep->h_scalars + (size_t)i0 * 32, (size_t)(i1 - i0) * 32,
+                              hipMemcpyHostToDevice, prep->copy_stream));
+        BP_TRY(hipEventRecord(prep->ev[ci], prep->copy_stream));
+        BP_TRY(hipStreamWaitEvent(st, prep->ev[ci], 0));
+        if (two_level)
+          hipLaunchKernelGGL(k_recode_coarse, dim3((i1 - i0 + CO_SCALARS - 1) / CO_SCALARS), dim3(1024), 0, st,
+                             (const uint8_t*)prep->d_stage, n32, i0, i1, pl, wc, nbin, codes, chist);
+        else
+          hipLaunchKernelGGL(k_recode_glv, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, (const uint8_t*)prep->d_stage, n32, i0,
+                             i1, pl, codes, ranks, hist);
+      }
+    } else if (two_level)
+      hipLaunchKernelGGL(k_recode_coarse, dim3((n32 + CO_SCALARS - 1) / CO_SCALARS), dim3(1024), 0, st, sc_part, n32, 0u, n32,
+                         pl, wc, nbin, codes, chist);
+    else if (glv)
+      hipLaunchKernelGGL(k_recode_glv, dim3((n32 + 255) / 256), dim3(256), 0, st, sc_part, n32, 0u, n32, pl, codes, ranks, hist);
+    if (glv && GLV_BITS + 1 - pl.c * (pl.W - 1) <= 5)
+      hipLaunchKernelGGL(k_rank_top, dim3((ne32 + 256 * RT_PER - 1) / (256 * RT_PER)), dim3(256), 0, st, ne32, pl, codes, ranks, hist);
+    if (!glv) hipLaunchKernelGGL(k_recode, dim3((n32 + 255) / 256), dim3(256), 0, st, sc_part, n32, pl, codes, ranks, hist);
+    if (two_level) {
+      // windows [0, wc): coarse partition by the high bucket bits, then the fine sort over tiles of every coarse bin
+      const uint32_t ncnt = (uint32_t)(wc * nbin);
+      // tiles that can exist: every bin rounds up once, on top of (entries of the windows) / FINE_TILE
+      const uint32_t tile_grid = (uint32_t)(ncnt + ((size_t)wc * ne32) / FINE_TILE);
+      hipLaunchKernelGGL(k_coarse_scan, dim3(1), dim3(1024), 0, st, chist, ncnt, cstart, ccur, tile_start, tile_bin,
+                         (uint32_t)max_tiles);
+      hipLaunchKernelGGL(k_scatter_coarse, dim3((ne32 + CO_TILE - 1) / CO_TILE), dim3(1024), 0, st, codes, ne32, pl, wc, nbin,
+                         ccur, ranks /* coarse entries */);
+      hipLaunchKernelGGL(k_fine_count, dim3(tile_grid), dim3(256), 0, st, ranks, cstart, chist, tile_start, tile_bin, ncnt, pl,
+                         nbin, hist, tbase);
+      hipLaunchKernelGGL(k_fine_place, dim3(tile_grid), dim3(256), 0, st, ranks, cstart, chist, tile_start, tile_bin, ncnt, pl,
+                         nbin, hist, tbase, offs, sorted);
+      if (wc < pl.W) {  // the narrow top window: ranks from k_rank_top, one scan and scatter for it alone
+        hipLaunchKernelGGL(k_scan, dim3(pl.W - wc), dim3(1024), 0, st, hist, ne32, pl, wc, offs, cursor);
+        hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W - wc), dim3(256), 0, st, codes, ranks, ne32, pl, wc, offs,
+                           sorted);
+      }
+    } else {
+      hipLaunchKernelGGL(k_scan, dim3(pl.W), dim3(1024), 0, st, hist, ne32, pl, 0, offs, cursor);
+      hipLaunchKernelGGL(k_scatter, dim3((ne32 + 255) / 256, pl.W), dim3(256), 0, st, codes, ranks, ne32, pl, 0, offs, sorted);
+    }
+    hipLaunchKernelGGL(k_cls_hist, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins);
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, st, bins);
+    hipLaunchKernelGGL(k_cls_scatter, dim3((nbt32 + 1023) / 1024), dim3(1024), 0, st, hist, nbt32, bins, order);
+    const bool prof_here = profile && part == 0;  // one event pair per call: the first piece's accumulation
+    if (prof_here) {  // the previous call's pair has completed on this in-order stream or is read after a sync
+      if (!ctx->msm_ev[0]) {
+        BP_TRY(hipEventCreate(&ctx->msm_ev[0]));
+        BP_TRY(hipEventCreate(&ctx->msm_ev[1]));
+      } else if (ctx->prof_pending_light) {
+        float ms = 0;
+        if (hipEventSynchronize(ctx->msm_ev[1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, ctx->msm_ev[0], ctx->msm_ev[1]) == hipSuccess) {
+          ctx->prof_ms[1] += ms;
+          ctx->prof_calls[1] += 1;
+        }
       }
     }
+    hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
+    if (prof_here) BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
+    {
+      const uint32_t light_blocks = (nbt32 + 255) / 256;
+      const uint32_t hgrid = (uint32_t)(max_slices < 1024 ? max_slices : 1024);
+      hipLaunchKernelGGL(k_accumulate, dim3(hgrid + light_blocks), dim3(256), 0, st, pt_part, hist, offs, sorted, order, bins,
+                         heavy_off, nbt32, glv, (uint32_t)pl.nb, shift_stride, hgrid, bk, partial);
+    }
+    if (prof_here) {
+      BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
+      ctx->prof_pending_light = true;
+      ctx->prof_madds[1] += (double)pl.W * ne32;
+    }
+    hipLaunchKernelGGL(k_heavy_final, dim3(fgrid), dim3(64), 0, st, order, bins, heavy_off, partial, bk);
   }
-  hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, st, hist, order, bins, heavy_off);
-  if (profile) BP_TRY(hipEventRecord(ctx->msm_ev[0], st));
-  {
-    const uint32_t light_blocks = (nbt32 + 255) / 256;
-    const uint32_t hgrid = (uint32_t)(max_slices < 1024 ? max_slices : 1024);
-    hipLaunchKernelGGL(k_accumulate, dim3(hgrid + light_blocks), dim3(256), 0, st, (const uint8_t*)d_points, hist, offs, sorted,
-                       order, bins, heavy_off, nbt32, glv, (uint32_t)pl.nb, shift_stride, hgrid, buckets, partial);
-  }
-  if (profile) {
-    BP_TRY(hipEventRecord(ctx->msm_ev[1], st));
-    ctx->prof_pending_light = true;
-    ctx->prof_madds[1] += (double)wn;
-  }
-  uint32_t fgrid = (uint32_t)(max_heavy < 4096 ? max_heavy : 4096);
-  hipLaunchKernelGGL(k_heavy_final, dim3(fgrid), dim3(64), 0, st, order, bins, heavy_off, partial, buckets);
+  if (parts_run > 1)
+    hipLaunchKernelGGL(k_add_bucket_arrays, dim3((nbt32 + 255) / 256), dim3(256), 0, st, buckets, nbt32, parts_run);
   if (prep) {  // all windows weigh 1: add their buckets index by index, then reduce ONE window; no Horner chain
     hipLaunchKernelGGL(k_combine_windows, dim3((pl.nb + 255) / 256), dim3(256), 0, st, buckets, (uint32_t)pl.W, (uint32_t)pl.nb);
     pl.W = 1;
@@ -1233,6 +1278,65 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
 int msm_run(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int c_override, void* d_out_affine,
             void* d_out_xyzz) {
   return msm_run_ws(ctx, MsmWsSource{nullptr, 0}, d_scalars, d_points, n, c_override, d_out_affine, d_out_xyzz);
+}
+
+// ---- scalars from host memory (include/bpgpu.h: bp_msm_dev_hs) ---------------------------------------------------------
+// Pieces of the point range.  32 MB of scalars take 0.63 ms to cross PCIe at N = 2^20 - a third of the sum's kernel time -
+// and nothing but the digit recoding (0.09 ms) can start before the LAST byte has landed unless the sum is cut by point
+// range, so that piece i's sort and accumulation run while piece i + 1 is in flight.  Measured on MI355X (bench.py sweep,
+// uniform scalars, ms at 2^18 / 2^19 / 2^20): 1 piece 1.36 / 1.85 / 2.79, 2 pieces 1.55 / 1.98 / 4.21, 3 pieces 1.96 /
+// 2.16 / 3.06, 4 pieces 3.34 / 2.39 / 3.14.  Copies that run beside kernels and the event hand-offs between the copy
+// stream and the compute stream cost more than the overlap returns (the same was found for the prepared-point upload
+// and for device-to-host copies in the verifier), so ONE piece is the default: the upload is then a
+// plain copy ahead of the kernels on the copy stream.  BP_MSM_HS_PARTS=2..8 selects the piecewise form (read per
+// call; tests/test_gpu_msm.py runs both).
+static int msm_hs_parts(size_t n) {
+  const char* e = getenv("BP_MSM_HS_PARTS");
+  const int v = e ? atoi(e) : 1;
+  return (v >= 2 && v <= 8 && n >= 4096) ? v : 1;
+}
+
+int msm_run_host_scalars(bp_ctx* ctx, const uint8_t* h_scalars, const void* d_points, size_t n, int c_override,
+                         void* d_out_affine) {
+  if (n == 0) return msm_run(ctx, nullptr, nullptr, 0, c_override, d_out_affine, nullptr);
+  if (!ctx->msm_copy_stream) {
+    BP_TRY(hipStreamCreateWithFlags(&ctx->msm_copy_stream, hipStreamNonBlocking));
+    for (auto& e : ctx->msm_copy_ev) BP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    BP_TRY(hipEventCreateWithFlags(&ctx->msm_stage_free, hipEventDisableTiming));
+  }
+  // the previous call's kernels may still read the staging buffer: the copies queue behind them
+  BP_TRY(hipEventRecord(ctx->msm_stage_free, ctx->stream));
+  BP_TRY(hipStreamWaitEvent(ctx->msm_copy_stream, ctx->msm_stage_free, 0));
+  if (ctx->msm_stage.bytes < n * 32) {
+    BP_TRY(hipStreamSynchronize(ctx->stream));  // a regrowth frees the old buffer
+    if (ctx->msm_stage.reserve(n * 32) != 0) {
+      ctx->err = "bp_msm_dev_hs: staging allocation failed";
+      return BP_ERR_NOMEM;
+    }
+  }
+  MsmHostScalars hs;
+  hs.h_scalars = h_scalars;
+  hs.d_stage = (uint8_t*)ctx->msm_stage.p;
+  hs.copy_stream = ctx->msm_copy_stream;
+  hs.ev = ctx->msm_copy_ev;
+  hs.parts = msm_hs_parts(n);
+  return msm_run_ws(ctx, MsmWsSource{nullptr, 0}, nullptr, d_points, n, c_override, d_out_affine, nullptr, nullptr, &hs);
+}
+
+void msm_host_scalars_release(bp_ctx* ctx) {
+  if (ctx->msm_copy_stream) {
+    (void)hipStreamSynchronize(ctx->msm_copy_stream);
+    (void)hipStreamDestroy(ctx->msm_copy_stream);
+    ctx->msm_copy_stream = nullptr;
+  }
+  for (auto& e : ctx->msm_copy_ev)
+    if (e) {
+      (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+  if (ctx->msm_stage_free) (void)hipEventDestroy(ctx->msm_stage_free);
+  ctx->msm_stage_free = nullptr;
+  ctx->msm_stage.release();
 }
 
 // ---- the entry point that allocates nothing (include/bpgpu.h: bp_msm_dev_static) -------------------------------

@@ -278,6 +278,14 @@ int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t 
   return msm_run(ctx, d_scalars, d_points, n, window_bits, d_out, nullptr);
 }
 
+int bp_msm_dev_hs(bp_ctx* ctx, const uint8_t* h_scalars, const void* d_points, size_t n, int window_bits, void* d_out) {
+  if (!ctx) return BP_ERR_ARG;
+  BP_REQUIRE(d_out && (n == 0 || (h_scalars && d_points)), "null pointer");
+  BP_REQUIRE(window_bits >= 0 && window_bits <= 16, "window_bits must be 0 (auto) or 1..16");
+  BP_TRY(hipSetDevice(ctx->device));
+  return msm_run_host_scalars(ctx, h_scalars, d_points, n, window_bits, d_out);
+}
+
 int bp_point_sum_dev(bp_ctx* ctx, const void* d_points, size_t n, void* d_out) {
   if (!ctx) return BP_ERR_ARG;
   BP_REQUIRE(d_out && (n == 0 || d_points), "null pointer");

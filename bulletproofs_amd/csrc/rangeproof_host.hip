@@ -142,7 +142,16 @@ struct bp_vjob {
   Pool* pool;
   void* pinned = nullptr;
   bool loaded = false;
+  // bp_vjob_submit / bp_vjob_wait: the run driven by a thread of its own, so that a second job's pass can fill the
+  // GPU while this one's drains
+  std::thread driver;
+  bool in_flight = false;
+  int driver_rc = BP_OK;
+  std::string driver_err;
+  std::vector<uint8_t> driver_verdicts;
 };
+
+static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err);
 
 extern "C" {
 
@@ -162,6 +171,7 @@ int bp_ctx_set_sqrt_branch(bp_ctx* ctx, int branch) {
 
 void bp_vjob_destroy(bp_vjob* job) {
   if (!job) return;
+  if (job->driver.joinable()) job->driver.join();  // a submitted pass finishes before its buffers go
   (void)hipSetDevice(job->ctx->device);
   for (auto& c : job->chunks)
     if (c.vb) bp_vbatch_destroy(c.vb);
@@ -236,6 +246,10 @@ int bp_vjob_load(bp_vjob* job, const uint8_t* scalars, const uint8_t* points) {
   if (!job) return BP_ERR_ARG;
   bp_ctx* ctx = job->ctx;
   BP_REQUIRE(scalars && points, "null pointer");
+  if (job->in_flight) {
+    ctx->err = "bp_vjob_load while a submitted pass is in flight (bp_vjob_wait first)";
+    return BP_ERR_STATE;
+  }
   BP_TRY(hipSetDevice(ctx->device));
   size_t Bt = job->batch;
   for (auto& ch : job->chunks) {
@@ -262,7 +276,75 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
     ctx->err = "bp_vjob_run before bp_vjob_load";
     return BP_ERR_STATE;
   }
-  BP_TRY(hipSetDevice(ctx->device));
+  if (job->in_flight) {
+    ctx->err = "bp_vjob_run while a submitted pass is in flight (bp_vjob_wait first)";
+    return BP_ERR_STATE;
+  }
+  std::string err;
+  int rc = vjob_run_impl(job, verdicts, err);
+  if (rc != BP_OK && !err.empty()) ctx->err = err;
+  return rc;
+}
+
+// Two jobs in flight: bp_vjob_submit starts the pass on a driver thread owned by the job and returns; bp_vjob_wait
+// joins it and hands out the verdicts.  While job A walks its last rounds and final multi-exponentiations (the GPU is
+// no longer full: the ends of a pass are ~16 % of it) job B's first stages already run.  Each job keeps its own
+// chunks, streams, pinned buffers and hashing pool; the two drivers only share the context's device and its
+// immutable generator tables.  Kernel timing (bp_ctx_profile) must be off while passes overlap.
+int bp_vjob_submit(bp_vjob* job) {
+  if (!job) return BP_ERR_ARG;
+  bp_ctx* ctx = job->ctx;
+  if (!job->loaded || job->in_flight) {
+    ctx->err = job->in_flight ? "bp_vjob_submit: the previous pass of this job has not been waited for"
+                              : "bp_vjob_submit before bp_vjob_load";
+    return BP_ERR_STATE;
+  }
+  if (ctx->profile) {
+    ctx->err = "bp_vjob_submit: kernel timing (bp_ctx_profile) covers synchronous passes only";
+    return BP_ERR_STATE;
+  }
+  if (job->driver.joinable()) job->driver.join();
+  job->driver_verdicts.assign(job->batch, 0);
+  job->driver_err.clear();
+  job->in_flight = true;
+  job->driver = std::thread([job] { job->driver_rc = vjob_run_impl(job, job->driver_verdicts.data(), job->driver_err); });
+  return BP_OK;
+}
+
+int bp_vjob_wait(bp_vjob* job, uint8_t* verdicts) {
+  if (!job) return BP_ERR_ARG;
+  bp_ctx* ctx = job->ctx;
+  BP_REQUIRE(verdicts, "null pointer");
+  if (!job->in_flight) {
+    ctx->err = "bp_vjob_wait without bp_vjob_submit";
+    return BP_ERR_STATE;
+  }
+  job->driver.join();
+  job->in_flight = false;
+  if (job->driver_rc != BP_OK) {
+    if (!job->driver_err.empty()) ctx->err = job->driver_err;
+    return job->driver_rc;
+  }
+  memcpy(verdicts, job->driver_verdicts.data(), job->batch);
+  return BP_OK;
+}
+
+}  // extern "C"
+
+// error reporting of the pass: into `err` (a driver thread must not write the context's message under another
+// call's feet); hipSetDevice is per thread
+#define VJ_TRY(expr)                                                   \
+  do {                                                                 \
+    hipError_t e_ = (expr);                                            \
+    if (e_ != hipSuccess) {                                            \
+      err = std::string(#expr) + ": " + hipGetErrorString(e_);        \
+      return BP_ERR_DEVICE;                                            \
+    }                                                                  \
+  } while (0)
+
+static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
+  bp_ctx* ctx = job->ctx;
+  VJ_TRY(hipSetDevice(ctx->device));
   const ShowStyle st = job->style;
   const uint32_t k = job->k;
   int rc;
@@ -441,6 +523,8 @@ int bp_vjob_run(bp_vjob* job, uint8_t* verdicts) {
 #undef TRACE
   return BP_OK;
 }
+
+extern "C" {
 
 // One job (workspaces in HBM, pinned staging, the hashing threads) stays cached on the context, so that repeated calls of
 // one shape - the shim's single-proof verifyProof in a loop, or `map verifyProof` batch after batch - do not

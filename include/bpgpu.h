@@ -110,6 +110,17 @@ int bp_point_on_curve(bp_ctx* ctx, const uint8_t* points, size_t n, uint8_t* ok)
  */
 int bp_msm(bp_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out);
 int bp_msm_dev(bp_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
+/* bp_msm_dev_hs     the same `sumExps` with the POINTS resident in HBM and the SCALARS still in host memory (pinned
+ *                   memory for the overlap below; pageable works, synchronously): a Pedersen vector commitment over
+ *                   resident generators whose exponents arrive per call (BASELINE config 3: "points uploaded once").
+ *                   One call instead of a copy, a synchronisation and bp_msm_dev.  BP_MSM_HS_PARTS=2..8 cuts the
+ *                   point range into pieces whose uploads are queued at once, piece i's bucket work running while
+ *                   piece i + 1 crosses PCIe (each piece fills its own bucket array, one reduction follows); on MI355X
+ *                   that overlap costs more than it returns, so the default is one piece.  Same result
+ *                   bytes as bp_msm_dev either way.
+ *                   Asynchronous on the context's stream; h_scalars must stay valid until that stream has passed the
+ *                   call (bp_ctx_sync). */
+int bp_msm_dev_hs(bp_ctx* ctx, const uint8_t* h_scalars, const void* d_points, size_t n, int window_bits, void* d_out);
 
 /* ---- multi-scalar multiplication over a FIXED point list ----
  * `sumExps es ps` where `ps` is the same list call after call - a Pedersen vector commitment over fixed generators,
@@ -266,6 +277,18 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
 void bp_vjob_destroy(bp_vjob* job);
 int bp_vjob_load(bp_vjob* job, const uint8_t* scalars, const uint8_t* points);
 int bp_vjob_run(bp_vjob* job, uint8_t* verdicts);
+/* bp_vjob_submit / bp_vjob_wait   bp_vjob_run in two halves, for a serving loop that keeps TWO jobs in flight on one
+ *                   context (`map verifyProof` over a stream of batches): submit starts the pass on a driver thread
+ *                   owned by the job and returns at once, wait blocks until it is done and returns its verdicts
+ *                   (the same bytes bp_vjob_run gives).  The beginning and the end of a pass leave the GPU partly
+ *                   idle (first hashes, last rounds, final multi-exponentiation of the last chunk: ~16 % of a
+ *                   65,536-proof pass); with a second job submitted meanwhile those ends overlap.  One pass per job at
+ *                   a time (BP_ERR_STATE otherwise: load / run / submit while in flight, wait without submit); the
+ *                   jobs must belong to the same context only in the sense that they share its generators - each has
+ *                   its own streams, buffers and hashing threads.  bp_ctx_profile must be off.  No counterpart in the
+ *                   reference (a pure function has no notion of overlap); the verdicts are its Bools. */
+int bp_vjob_submit(bp_vjob* job);
+int bp_vjob_wait(bp_vjob* job, uint8_t* verdicts);
 
 /* ---- prover path ----
  *

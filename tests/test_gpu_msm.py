@@ -173,3 +173,55 @@ def test_prepared_points_full_size_structured_scalars(engine, kind):
     engine.sync()
     assert _lib.dec_point(bytes(d_o.cpu().numpy())) == exp
     mp.close()
+
+
+# ---- bp_msm_dev_hs: scalars from host memory, uploaded in pieces behind which the bucket work runs -------------------
+@pytest.mark.parametrize("kind", ["uniform", "64bit", "01", "minus1"])
+def test_host_scalar_msm_in_pieces(engine, kind):
+    """2^19 + 777 points with known discrete logs, in one piece (the default) and in two / three uneven pieces
+    (BP_MSM_HS_PARTS, each piece with its own bucket array): the result must be (sum e_i k_i mod r) * G and byte-equal to
+    bp_msm_dev's, from pinned and from pageable scalars, call after call on one context (the staging buffer is reused);
+    small sums and n = 0 as well.  `minus1`: scalars in {0, r - 1},
+    the shape of aR in commitBitVectors (RangeProof/Internal.hs:136-147)."""
+    import numpy as np
+    import torch
+    n = (1 << 19) + 777
+    rng = np.random.default_rng(170)
+    ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x7F
+    g = np.frombuffer(_lib.enc_point(o.GEN), dtype=np.uint8)
+    pts = np.frombuffer(engine.point_mul_raw(ks.tobytes(), np.tile(g, n).tobytes(), n), dtype=np.uint8).copy()
+    es = np.zeros((n, 32), dtype=np.uint8)
+    if kind == "uniform":
+        es[:] = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        es[:, 31] &= 0x7F
+    elif kind == "64bit":
+        es[:, :8] = rng.integers(0, 256, size=(n, 8), dtype=np.uint8)
+    elif kind == "01":
+        es[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint8)
+    else:
+        rm1 = np.frombuffer(_lib.enc_scalar(R - 1), dtype=np.uint8)
+        es[rng.integers(0, 2, size=n).astype(bool)] = rm1
+    k_int = [int.from_bytes(bytes(r_), "little") for r_ in ks]
+    e_int = [int.from_bytes(bytes(r_), "little") for r_ in es]
+    d_p = torch.from_numpy(pts).cuda()
+    h_s = torch.from_numpy(es).pin_memory()
+    d_s = h_s.cuda()
+    d_o = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    d_r = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    import os
+    try:
+        for parts, m in ((1, n), (2, n), (2, 5000), (3, n), (1, 5000), (2, 1), (1, 0), (2, n)):
+            os.environ["BP_MSM_HS_PARTS"] = str(parts)
+            exp = o.point_mul(o.GEN, sum(a * b for a, b in zip(e_int[:m], k_int[:m])) % R)
+            engine.msm_dev(d_s.data_ptr(), d_p.data_ptr(), m, d_r.data_ptr())
+            engine.msm_dev_hs(h_s.data_ptr(), d_p.data_ptr(), m, d_o.data_ptr())
+            engine.sync()
+            assert _lib.dec_point(bytes(d_o.cpu().numpy())) == exp, (kind, parts, m)
+            assert torch.equal(d_o, d_r)
+        pageable = es.copy()
+        engine.msm_dev_hs(pageable.ctypes.data, d_p.data_ptr(), n, d_o.data_ptr())
+        engine.sync()
+        assert torch.equal(d_o, d_r)
+    finally:
+        del os.environ["BP_MSM_HS_PARTS"]

@@ -53,3 +53,49 @@ def test_batch_of_generated_proofs_verifies(engine):
     exp[bad] = False
     got = np.array(engine.verify_batch(n, 1, B, sc.tobytes(), pts.tobytes()))
     assert (got == exp).all()
+
+
+def test_two_jobs_in_flight_give_the_same_verdicts(engine):
+    """bp_vjob_submit / bp_vjob_wait: two jobs overlapping on one context return exactly what bp_vjob_run returns for
+    each of them, pass after pass (different batches, different corrupted proofs, chunked and single-chunk jobs), and
+    the state rules hold (no second pass, load or run while one is in flight; no wait without submit)."""
+    import ctypes
+    import proofgen
+    engine.set_generators(o.gs(128), o.hs(128), o.h())
+    n = 64
+    jobs, expect = [], []
+    for seed, B, chunks in ((11, 9000, 2), (12, 5000, 1)):
+        inp = proofgen.random_inputs(seed, n, B)
+        sc, pts = proofgen.make_proofs(engine, _lib.enc_point(o.h()), n, B, inp, threads=4)
+        bad = np.random.default_rng(seed).choice(B, size=B // 50, replace=False)
+        sc[2, bad, 0] ^= 1
+        exp = np.ones(B, dtype=np.uint8)
+        exp[bad] = 0
+        job = engine.vjob(n, 1, B, chunks, 4)
+        job.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
+        assert (np.frombuffer(job.run(), dtype=np.uint8) == exp).all()
+        jobs.append((job, sc, pts))
+        expect.append(exp)
+    a, b = jobs[0][0], jobs[1][0]
+    with pytest.raises(_lib.BpError):
+        a.wait()                                # nothing submitted
+    a.submit()
+    b.submit()
+    with pytest.raises(_lib.BpError):
+        a.submit()                              # one pass per job at a time
+    with pytest.raises(_lib.BpError):
+        a.run()
+    with pytest.raises(_lib.BpError):
+        a.load(jobs[0][1].ctypes.data_as(ctypes.c_char_p), jobs[0][2].ctypes.data_as(ctypes.c_char_p))
+    for _ in range(3):                          # steady state: a new pass of A is submitted while B is still running
+        va = np.frombuffer(a.wait(), dtype=np.uint8)
+        a.submit()
+        vb = np.frombuffer(b.wait(), dtype=np.uint8)
+        b.submit()
+        assert (va == expect[0]).all() and (vb == expect[1]).all()
+    assert (np.frombuffer(a.wait(), dtype=np.uint8) == expect[0]).all()
+    assert (np.frombuffer(b.wait(), dtype=np.uint8) == expect[1]).all()
+    assert (np.frombuffer(a.run(), dtype=np.uint8) == expect[0]).all()   # the synchronous form still works afterwards
+    b.submit()
+    b.close()                                   # destroying a job joins its pass first
+    a.close()
