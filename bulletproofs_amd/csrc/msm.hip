@@ -740,6 +740,38 @@ __global__ void __launch_bounds__(256) k_seg_reduce(const xyzz* __restrict__ buc
   st_xyzz(&segv[t], segment_value(pl, sg, S, T));
 }
 
+// The same with every segment spread over a quad of lanes (lanes29.h): the 2 seg additions and the multiplication by the
+// segment index are one dependent chain (~40 point operations), 3.1 / 2.7 us per addition / doubling on a quad against
+// 5.7 / 4.2 us in one lane.  Used while four lanes per segment still fit one wave per SIMD (W nseg <= 16,384: the
+// 14-bit plans of 2^14..2^17 terms); at 2^20 (36,864 segments) the quad form puts two waves on every SIMD and gains
+// nothing.  Identity operands (empty buckets, S before the first non-empty bucket) are answered by selects.
+__global__ void __launch_bounds__(256) k_seg_reduce_quad(const xyzz* __restrict__ buckets, MsmPlan pl, int seg_log,
+                                                        int idx_bits, xyzz* __restrict__ segv) {
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, lane = threadIdx.x & 3u;
+  const uint32_t total = (uint32_t)pl.W * pl.nseg;
+  if (t >= total) return;  // whole quads leave together
+  const uint32_t sg = t % (uint32_t)pl.nseg;
+  const xyzz* base = buckets + (size_t)t * pl.seg;
+  fe29 S = fe29_zero(), T = fe29_zero();
+#pragma unroll 1
+  for (int j = pl.seg - 1; j >= 0; j--) {
+    S = quad_add_total(S, quad_load(&base[j], lane), lane);
+    T = quad_add_total(T, S, lane);
+  }
+  // segment_value: T + (sg * seg) * S, the small multiple by double-and-add from the top bit of sg
+  fe29 m = fe29_zero();
+#pragma unroll 1
+  for (int i = idx_bits - 1; i >= 0; i--) {
+    m = quad_dbl(m, lane);
+    const fe29 a = quad_add_total(m, S, lane);
+    m = fe29_sel(((sg >> i) & 1u) != 0u, a, m);
+  }
+#pragma unroll 1
+  for (int i = 0; i < seg_log; i++) m = quad_dbl(m, lane);
+  T = quad_add_total(T, m, lane);
+  quad_store(&segv[t], T, lane);
+}
+
 // ---- 7. window sums ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_window_sum(const xyzz* __restrict__ segv, MsmPlan pl,
                                                    xyzz* __restrict__ wsum) {
@@ -1259,7 +1291,14 @@ static int msm_run_ws(bp_ctx* ctx, const MsmWsSource& wsrc, const void* d_scalar
     return BP_OK;
   }
   uint32_t nsegt = (uint32_t)pl.W * pl.nseg;
-  hipLaunchKernelGGL(k_seg_reduce, dim3((nsegt + 255) / 256), dim3(256), 0, st, buckets, pl, segv);
+  static const bool seg_quad = !(getenv("BP_MSM_SEG_QUAD") && atoi(getenv("BP_MSM_SEG_QUAD")) == 0);
+  if (seg_quad && nsegt <= 16384 && pl.nseg > 1) {
+    int seg_log = 0, idx_bits = 1;
+    while ((1 << seg_log) < pl.seg) seg_log++;
+    while ((1 << idx_bits) < pl.nseg) idx_bits++;
+    hipLaunchKernelGGL(k_seg_reduce_quad, dim3((nsegt * 4 + 255) / 256), dim3(256), 0, st, buckets, pl, seg_log, idx_bits, segv);
+  } else
+    hipLaunchKernelGGL(k_seg_reduce, dim3((nsegt + 255) / 256), dim3(256), 0, st, buckets, pl, segv);
   // window sums: 16 slices per window by quads, then the 16 partial sums (0.04 ms against 0.22 ms for one workgroup of
   // single lanes per window).  BP_MSM_QUAD=0 keeps the one-lane kernel.
   static const bool tail_quad = !(getenv("BP_MSM_QUAD") && atoi(getenv("BP_MSM_QUAD")) == 0);
