@@ -1338,6 +1338,21 @@ static int msm_hs_parts(size_t n) {
 int msm_run_host_scalars(bp_ctx* ctx, const uint8_t* h_scalars, const void* d_points, size_t n, int c_override,
                          void* d_out_affine) {
   if (n == 0) return msm_run(ctx, nullptr, nullptr, 0, c_override, d_out_affine, nullptr);
+  const int parts = msm_hs_parts(n);
+  if (ctx->msm_stage.bytes < n * 32) {
+    BP_TRY(hipStreamSynchronize(ctx->stream));  // a regrowth frees the old buffer
+    if (ctx->msm_copy_stream) BP_TRY(hipStreamSynchronize(ctx->msm_copy_stream));
+    if (ctx->msm_stage.reserve(n * 32) != 0) {
+      ctx->err = "bp_msm_dev_hs: staging allocation failed";
+      return BP_ERR_NOMEM;
+    }
+  }
+  if (parts == 1) {
+    // one piece: the copy is simply the first command of the sum on the context's own stream - no second stream, no
+    // event hand-offs (they cost ~0.1 ms per call, measured) - and the stream's order protects the staging buffer
+    BP_TRY(hipMemcpyAsync(ctx->msm_stage.p, h_scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return msm_run_ws(ctx, MsmWsSource{nullptr, 0}, ctx->msm_stage.p, d_points, n, c_override, d_out_affine, nullptr);
+  }
   if (!ctx->msm_copy_stream) {
     BP_TRY(hipStreamCreateWithFlags(&ctx->msm_copy_stream, hipStreamNonBlocking));
     for (auto& e : ctx->msm_copy_ev) BP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1346,19 +1361,12 @@ int msm_run_host_scalars(bp_ctx* ctx, const uint8_t* h_scalars, const void* d_po
   // the previous call's kernels may still read the staging buffer: the copies queue behind them
   BP_TRY(hipEventRecord(ctx->msm_stage_free, ctx->stream));
   BP_TRY(hipStreamWaitEvent(ctx->msm_copy_stream, ctx->msm_stage_free, 0));
-  if (ctx->msm_stage.bytes < n * 32) {
-    BP_TRY(hipStreamSynchronize(ctx->stream));  // a regrowth frees the old buffer
-    if (ctx->msm_stage.reserve(n * 32) != 0) {
-      ctx->err = "bp_msm_dev_hs: staging allocation failed";
-      return BP_ERR_NOMEM;
-    }
-  }
   MsmHostScalars hs;
   hs.h_scalars = h_scalars;
   hs.d_stage = (uint8_t*)ctx->msm_stage.p;
   hs.copy_stream = ctx->msm_copy_stream;
   hs.ev = ctx->msm_copy_ev;
-  hs.parts = msm_hs_parts(n);
+  hs.parts = parts;
   return msm_run_ws(ctx, MsmWsSource{nullptr, 0}, nullptr, d_points, n, c_override, d_out_affine, nullptr, nullptr, &hs);
 }
 
