@@ -312,24 +312,44 @@ BP_HD fe29 fe29_norm(const fe29& a) {
 
 // Reduction of 17 product columns (each < 2^63.9) to class N.
 BP_HD fe29 fe29_reduce(uint64_t (&c)[17]) {
-  // 2^(29 k) = 2^(29 (k - 9)) (2^37 + 31264) for k >= 9; c = lo + 2^32 hi:
-  //   lo * 31264 -> column k-9,  lo * 2^8 and hi * 2^3 * 31264 -> column k-8,  hi * 2^11 -> column k-7
+  // 2^(29 k) = 2^(29 (k - 9)) (2^37 + 31264) for k >= 9.  A high column c = lo + 2^32 hi first hands hi to the column
+  // above it (2^32 2^(29 k) = 8 * 2^(29 (k + 1)); what arrives is below 2^35), so that columns 9..15 fold with two
+  // multiply-adds each: lo * 31264 -> column k-9, lo * 2^8 -> column k-8.  Column 16 keeps what it was handed and
+  // folds its hi as well: hi * 2^3 * 31264 -> column 8, and hi * 2^11 of column 9 once more, hi * 2^11 * 31264 ->
+  // column 0, hi * 2^19 -> column 1.  26 multiply-adds (3 x 7 + 5) against the 32 of folding lo and hi of every column.
 #pragma unroll
-  for (int k = 16; k >= 9; k--) {
+  for (int k = 9; k < 16; k++) {
     const uint32_t lo = (uint32_t)c[k], hi = (uint32_t)(c[k] >> 32);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE29_PORTABLE)
-    asm("v_mad_u64_u32 %0, vcc, %3, %5, %0\n\t"
+    asm("v_mad_u64_u32 %2, vcc, %4, 8, %2\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %5, %0\n\t"
         "v_mad_u64_u32 %1, vcc, %3, %6, %1\n\t"
-        "v_mad_u64_u32 %2, vcc, %4, %7, %2\n\t"
-        "v_mad_u64_u32 %1, vcc, %4, %8, %1\n\t"
-        : "+v"(c[k - 9]), "+v"(c[k - 8]), "+v"(c[k - 7])
-        : "v"(lo), "v"(hi), "s"(31264u), "s"(256u), "s"(2048u), "s"(250112u)
+        : "+v"(c[k - 9]), "+v"(c[k - 8]), "+v"(c[k + 1])
+        : "v"(lo), "v"(hi), "s"(31264u), "s"(256u)
         : "vcc");
 #else
+    mad29k(c[k + 1], hi, 8u);
     mad29k(c[k - 9], lo, 31264u);
     mad29k(c[k - 8], lo, 256u);
-    mad29k(c[k - 7], hi, 2048u);
-    mad29k(c[k - 8], hi, 250112u);
+#endif
+  }
+  {
+    const uint32_t lo = (uint32_t)c[16], hi = (uint32_t)(c[16] >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BP_FE29_PORTABLE)
+    asm("v_mad_u64_u32 %0, vcc, %5, %9, %0\n\t"
+        "v_mad_u64_u32 %2, vcc, %4, %6, %2\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %10, %1\n\t"
+        "v_mad_u64_u32 %3, vcc, %4, %7, %3\n\t"
+        "v_mad_u64_u32 %3, vcc, %5, %8, %3\n\t"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[7]), "+v"(c[8])
+        : "v"(lo), "v"(hi), "s"(31264u), "s"(256u), "s"(250112u), "s"(64028672u), "s"(524288u)
+        : "vcc");
+#else
+    mad29k(c[7], lo, 31264u);
+    mad29k(c[8], lo, 256u);
+    mad29k(c[8], hi, 250112u);
+    mad29k(c[0], hi, 64028672u);
+    mad29k(c[1], hi, 524288u);
 #endif
   }
   fe29 r;
