@@ -367,6 +367,7 @@ def main():
                     help="auto = weak (the headline); the split of BASELINE config 4 is then reported as strong_split")
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--pipe-chunks", type=int, default=0, help="chunks per job of the two-jobs-in-flight leg")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="transcript-hashing threads per rank (0 = min(16, usable cores / ranks on this host))")
     ap.add_argument("--pin", type=int, default=1, help="with several ranks on a host: restrict each rank to its own cores")
@@ -475,24 +476,26 @@ def main():
                                          what="bp_rangeproof_verify_batch from pageable host buffers: first call "
                                               "(creates and caches the job on the context), then a second call"))
     # Two jobs in flight (bp_vjob_submit / bp_vjob_wait): what a serving loop over a stream of 65,536-proof batches gets.
-    # The headline above stays the synchronous step; this rate is reported beside it.
+    # The headline above stays the synchronous step; this rate is reported beside it.  The hardware runs four of the
+    # library's streams side by side, so two jobs in flight take TWO chunks each (four kernels of twice the width):
+    # 21.8 ms per pass against 24.1 ms with four chunks each (benchmarks/pipe_sweep.sh).
     pipelined = None
     if a.extras:
-        job2 = eng.vjob(n_bits, 1, B, a.chunks, host_threads)
-        job2.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
-        check(job2.run())
+        pj = [eng.vjob(n_bits, 1, B, a.pipe_chunks, host_threads) for _ in range(2)]
+        for j in pj:
+            j.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
+            check(j.run())
         npass = max(4, a.steps)
         barrier()
         t0 = time.perf_counter()
-        job.submit()
-        job2.submit()
+        pj[0].submit()
+        pj[1].submit()
         outs = []
         for i in range(npass - 2):          # pass i is collected, pass i + 2 submitted on the same job
-            j = job if i % 2 == 0 else job2
-            outs.append(j.wait())
-            j.submit()
-        outs.append((job if (npass - 2) % 2 == 0 else job2).wait())
-        outs.append((job if (npass - 1) % 2 == 0 else job2).wait())
+            outs.append(pj[i % 2].wait())
+            pj[i % 2].submit()
+        outs.append(pj[(npass - 2) % 2].wait())
+        outs.append(pj[(npass - 1) % 2].wait())
         barrier()
         dp = time.perf_counter() - t0
         for v in outs:
@@ -502,9 +505,12 @@ def main():
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             dp = float(tp.item())
         pipelined = dict(value=total * npass / dp, unit="verifies/s", passes=npass, ms_per_pass=dp / npass * 1e3,
-                         what="two jobs of %d proofs per GPU in flight on one context (bp_vjob_submit / bp_vjob_wait): "
-                              "the fill and drain of consecutive passes overlap; every verdict checked" % B)
-        job2.close()
+                         chunks_per_job=a.pipe_chunks,
+                         what="two jobs of %d proofs per GPU in flight on one context (bp_vjob_submit / bp_vjob_wait), "
+                              "%d chunks per job: the latency-bound rounds of one pass run beside the wide kernels of "
+                              "the other; every verdict checked" % (B, a.pipe_chunks))
+        for j in pj:
+            j.close()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -1,5 +1,5 @@
 """Steady-state probe of the batch verifier: N passes over the same 65,536 proofs, synchronous (one job) or with two
-jobs in flight (bp_vjob_submit / bp_vjob_wait).  Run under rocprofv3 --kernel-trace and feed the .db to
+(mode "pipe") or J (mode "pipeJ", e.g. pipe3) jobs in flight (bp_vjob_submit / bp_vjob_wait).  Run under rocprofv3 --kernel-trace and feed the .db to
 benchmarks/prof_window.py to see how busy the GPU is inside the passes."""
 import ctypes
 import os
@@ -23,26 +23,28 @@ eng = Engine(0)
 _, _, h = eng.derive_generators(64)
 inp = proofgen.random_inputs(4, 64, B)
 sc, pts = proofgen.make_proofs(eng, _lib.enc_point(h), 64, B, inp, threads=16)
-jobs = [eng.vjob(64, 1, B, chunks, threads) for _ in range(2 if mode == "pipe" else 1)]
+njobs = 1 if mode == "sync" else (int(mode[4:]) if len(mode) > 4 else 2)
+jobs = [eng.vjob(64, 1, B, chunks, threads) for _ in range(njobs)]
 for j in jobs:
     j.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
     v = np.frombuffer(j.run(), dtype=np.uint8)
     assert v.all()
 t0 = time.perf_counter()
-if mode == "pipe":
-    jobs[0].submit()
-    jobs[1].submit()
-    for i in range(passes - 2):
-        j = jobs[i % 2]
+if njobs > 1:
+    for j in jobs:
+        j.submit()
+    for i in range(passes - njobs):
+        j = jobs[i % njobs]
         j.wait()
         j.submit()
-    jobs[(passes - 2) % 2].wait()
-    jobs[(passes - 1) % 2].wait()
+    for i in range(passes - njobs, passes):
+        jobs[i % njobs].wait()
 else:
     for _ in range(passes):
         jobs[0].run()
 dt = time.perf_counter() - t0
-print("%s: %d passes of %d proofs, %.2f ms per pass, %.3f M verifies/s" % (mode, passes, B, dt / passes * 1e3, B * passes / dt / 1e6))
+print("%s chunks=%d threads=%d: %d passes of %d proofs, %.2f ms per pass, %.3f M verifies/s"
+      % (mode, chunks, threads, passes, B, dt / passes * 1e3, B * passes / dt / 1e6))
 for j in jobs:
     j.close()
 eng.close()

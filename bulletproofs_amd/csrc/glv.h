@@ -247,6 +247,61 @@ BP_HD xyzz glv_pair_multiexp_tab29(const u256& k0, const u256& k1, LoadAff load)
   return xyzz29_to(acc);
 }
 
+// NT sign-free joint tables on ONE doubling chain: sum over t of k[2t] P_t0 + k[2t+1] P_t1, load(t, e) the AFFINE
+// entry e in [1, 16) of table t as above.  A table of a single point (present[2t+1] false) has entries 1..3 only; its
+// absent half-scalars stay zero, so nothing above 3 is ever asked for.  One doubling and up to NT mixed additions
+// per bit through ONE addition site; the entries of the next bit are requested before the current step's arithmetic.
+template <int NT, class LoadAff>
+BP_HD xyzz glv_tables_multiexp29(const u256 (&k)[2 * NT], const bool (&present)[2 * NT], LoadAff load) {
+  static_assert(NT == 1 || NT == 2, "one or two tables per chain");
+  BitReg b[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      GlvPos s;
+#pragma unroll
+      for (int i = 0; i < 5; i++) s.m1[i] = s.m2[i] = 0;
+      if (present[2 * t + j]) s = glv_split_pos(k[2 * t + j]);
+      b[t][2 * j] = bitreg_init5(s.m1);
+      b[t][2 * j + 1] = bitreg_init5(s.m2);
+    }
+  uint32_t idx[NT];
+  affine q[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    idx[t] = bitreg_next(b[t][0]) | (bitreg_next(b[t][1]) << 1) | (bitreg_next(b[t][2]) << 2) | (bitreg_next(b[t][3]) << 3);
+    q[t] = load(t, (int)(idx[t] ? idx[t] : 1u));
+  }
+  xyzz29 acc = xyzz29_inf();
+#pragma unroll 1
+  for (int i = 0; i < GLV_BITS; i++) {
+    affine cur[NT];
+    uint32_t icur[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      cur[t] = q[t];
+      icur[t] = idx[t];
+      idx[t] = 0u;
+      if (i + 1 < GLV_BITS)
+        idx[t] = bitreg_next(b[t][0]) | (bitreg_next(b[t][1]) << 1) | (bitreg_next(b[t][2]) << 2) | (bitreg_next(b[t][3]) << 3);
+      q[t] = load(t, (int)(idx[t] ? idx[t] : 1u));
+    }
+    acc = xyzz29_dbl(acc);
+    if constexpr (NT == 1) {
+      if (icur[0] && !affine_is_inf(cur[0])) acc = xyzz29_madd(acc, cur[0], false);
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < NT; t++) {
+        const affine c = t ? cur[NT - 1] : cur[0];
+        const uint32_t ic = t ? icur[NT - 1] : icur[0];
+        if (ic && !affine_is_inf(c)) acc = xyzz29_madd(acc, c, false);
+      }
+    }
+  }
+  return xyzz29_to(acc);
+}
+
 // ---- k*P with one lane per bit -------------------------------------------------------------------------------
 // Lane j < GLV_LANE_BITS holds Tj = 2^j P (XYZZ) and contributes [bit j of |k1|] (+-Tj) + [bit j of |k2|] (+-phi(Tj)),
 // k = k1 + k2*lambda the signed split: no doubling and at most one addition per lane, and the lanes' terms add up

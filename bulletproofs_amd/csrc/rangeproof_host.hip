@@ -122,6 +122,12 @@ int default_threads() {
   return t > 16 ? 16 : t;
 }
 
+// BP_FS_DEVICE=0 keeps the Fiat-Shamir transcript on the host for every batch size
+bool fs_device_enabled() {
+  static const bool on = !(getenv("BP_FS_DEVICE") && atoi(getenv("BP_FS_DEVICE")) == 0);
+  return on;
+}
+
 struct Chunk {
   bp_vbatch* vb = nullptr;
   uint32_t B = 0;       // proofs in this chunk
@@ -186,8 +192,10 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
   BP_REQUIRE(out, "null pointer");
   *out = nullptr;
   BP_REQUIRE(batch >= 1, "batch must be >= 1");
-  // chunks ping-pong between host hashing and the GPU; four streams of the context's concurrent set overlap
-  if (n_chunks == 0) n_chunks = batch >= 16384 ? 4 : (batch >= 4096 ? 2 : 1);
+  // Host transcript: chunks ping-pong between host hashing and the GPU; four streams of the context's concurrent set
+  // overlap.  Device transcript (the default, fs_device_enabled): no host step inside a pass, so ONE chunk - its chain
+  // kernels then have a wave on every SIMD and its multi-exponentiations several.
+  if (n_chunks == 0) n_chunks = fs_device_enabled() ? 1 : (batch >= 16384 ? 4 : (batch >= 4096 ? 2 : 1));
   BP_REQUIRE(n_chunks <= 64 && n_chunks <= batch, "n_chunks out of range");
   BP_TRY(hipSetDevice(ctx->device));
   bp_vjob* job = new bp_vjob();
@@ -353,6 +361,26 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   auto t_entry = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
 #define TRACE(what, c, r, t0) do { if (trace) fprintf(stderr, "[vjob] %-8s chunk %d round %d  %8.3f -> %8.3f ms\n", what, (int)(c), (int)(r), t0, now_ms()); } while (0)
+  // The transcript on the device (BP_FS_DEVICE, default on): every chunk's pass is one in-order sequence of kernels,
+  // challenges included, and the host only collects verdicts.  The latency path of small batches keeps the host
+  // transcript (its chains run one lane per scalar bit and hand XYZZ sums to the host anyway).
+  bool fsdev = fs_device_enabled();
+  for (auto& ch : job->chunks) fsdev = fsdev && !ch.vb->split;
+  if (fsdev) {
+    for (auto& ch : job->chunks)
+      if ((rc = vbatch_run_fsdev_async(ch.vb, ch.verdict)) != BP_OK) {
+        err = ctx->err;
+        return rc;
+      }
+    for (auto& ch : job->chunks) {
+      if ((rc = vbatch_wait(ch.vb)) != BP_OK) {
+        err = ctx->err;
+        return rc;
+      }
+      memcpy(verdicts + ch.first, ch.verdict, ch.B);
+    }
+    return BP_OK;
+  }
   const ShaMid r_mid = sha_mid_show_r();  // every transcript opens with the first block of `show _r`
   // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
   // Two proofs are hashed side by side (finish_fr_pair: interleaved SHA-256 chains); a lone last proof pairs

@@ -58,8 +58,10 @@ struct bp_vbatch {
   uint64_t epoch;         // ctx->gen_epoch at creation: the generator set the term tables refer to
   bp::u256 *cst, *ypowinv, *zpow, *xk_m /* x_k^2 */, *xkinv_m, *stab /* half-tables of the s-vector */;
   uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
-  bp::xyzz *acc1, *acc2, *vtab, *vtab2;  // vtab2: joint tables of the t-check (runs beside the rounds)
-  // joint tables of the rounds: affine entries, and the XYZZ composites / running products they are normalised from
+  bp::xyzz *acc1, *acc2, *vtab;  // vtab: S and phi(S) per proof (k_stage1_tail_pair)
+  uint32_t* fsmsg;               // message buffers of the device transcript (fsdev.h), FS_MSG_WORDS x B words
+  // joint tables of the rounds, of S and of the t-check's terms (k_round_tables): affine entries, and the XYZZ
+  // composites / running products they are normalised from
   uint8_t* rtab;
   bp::xyzz* rtx;
   bp::u256* rpre;
@@ -78,6 +80,7 @@ struct bp_vbatch {
   bool direct_host;
   // profiling: event pairs around the three k_fixed_multiexp launches
   hipEvent_t ev[3][2];
+  hipEvent_t fs_ev[3];  // device-transcript pass: hand-offs between the batch's stream and its side stream
   hipEvent_t done;  // recorded behind the last command of each *_async call (vbatch_ready)
   bool ev_pending[3];
   double ev_madds[3];
@@ -98,6 +101,8 @@ int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t*
 // the pass's challenge-independent side work (L_r, R_r text into lr_text, the rounds' joint tables), ahead of begin
 int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
+// the whole pass with the Fiat-Shamir transcript on the device (fsdev.h): no host step between load and verdicts
+int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts);
 int vbatch_wait(bp_vbatch* vb);
 // bp_vbatch_create with the caller's promise to set bp_vbatch::pfor (its threads run the latency path's host loops)
 int vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, bool pooled_host, bp_vbatch** out);

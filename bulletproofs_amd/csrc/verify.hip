@@ -23,6 +23,7 @@
 #include "fixedbase.h"
 #include "fq29.h"
 #include "lanes29.h"
+#include "fsdev.h"
 #include "glv.h"
 #include "host_inv.h"
 #include "verify.h"
@@ -333,103 +334,67 @@ __global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk /* <= 64 */, con
   if (threadIdx.x == 0) st_xyzz(&acc_out[p], acc);
 }
 
-// ---- variable-base terms: GLV halves + joint (Straus) tables in global memory (glv.h) ----------
-// Table entry e (1-based) of table t for proof p lives at tab[(15*t + e - 1) * B + p].
-constexpr int VT_ENTRIES = 18;  // up to three points: one 4-term table (15) + one 2-term table (3)
-
-template <int NP>
-__device__ __forceinline__ xyzz glv_multiexp_dev(const u256 (&k)[NP], const affine (&P)[NP], xyzz* __restrict__ tab,
-                                                 size_t B, size_t p) {
-  // table 0: points 0 (and 1); table 1 (entries 16..18): point 2
-  auto store0 = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(e - 1) * B + p], v); };
-  auto load0 = [&](int e) { return ld_xyzz(&tab[(size_t)(e - 1) * B + p]); };
-  auto store1 = [&](int e, const xyzz& v) { st_xyzz(&tab[(size_t)(15 + e - 1) * B + p], v); };
-  auto load1 = [&](int e) { return ld_xyzz(&tab[(size_t)(15 + e - 1) * B + p]); };
-  HalfPair h0 = glv_prep_point(k[0], P[0], 1, 2, store0);
-  HalfPair h1 = h0, h2 = h0;
-  if constexpr (NP >= 2) h1 = glv_prep_point(k[1], P[1], 4, 8, store0);
-  if constexpr (NP >= 3) h2 = glv_prep_point(k[2], P[2], 1, 2, store1);
-  joint_table_composites<(NP >= 2 ? 4 : 2)>(store0, load0);
-  if constexpr (NP >= 3) joint_table_composites<2>(store1, load1);
-  // the chain on nine 29-bit limbs (fq29.h): lazy doubling, lazy full addition of the XYZZ table entries; ONE addition
-  // site serves both tables
-  xyzz29 acc = xyzz29_inf();
-#pragma unroll 1
-  for (int i = 0; i < GLV_BITS; i++) {
-    uint32_t idx0 = bitreg_next(h0.a) | (bitreg_next(h0.b) << 1), idx1 = 0;
-    if constexpr (NP >= 2) idx0 |= (bitreg_next(h1.a) << 2) | (bitreg_next(h1.b) << 3);
-    if constexpr (NP >= 3) idx1 = bitreg_next(h2.a) | (bitreg_next(h2.b) << 1);
-    acc = xyzz29_dbl(acc);
-#pragma unroll 1
-    for (int t = 0; t < (NP >= 3 ? 2 : 1); t++) {
-      const uint32_t idx = t ? idx1 : idx0;
-      if (idx) acc = xyzz29_add(acc, xyzz29_from(t ? load1((int)idx) : load0((int)idx)));
-    }
-  }
-  return xyzz29_to(acc);
-}
-
-// stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
-                                                    const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
-                                                    xyzz* __restrict__ tab, uint8_t* __restrict__ acc_aff /*[B][64]*/,
-                                                    uint8_t* __restrict__ host_out /*pinned host copy, or null*/,
-                                                    uint8_t* __restrict__ host_txt /*pinned [B][2][80] decimal text, or null*/) {
-  __shared__ uint32_t lds[256 * 2 * DEC_REC_WORDS];
-  // the host waits for this kernel (it hashes P next): its waves take issue priority over the throughput
-  // kernels of other chunks that share the SIMDs
-  __builtin_amdgcn_s_setprio(3);
-  __shared__ u256 inv_lds[BATCHINV_LDS];
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < d.B;
-  xyzz acc = xyzz_inf();
-  if (live) {
-    size_t B = d.B;
-    u256 k[1] = {Fr::from_mont(ldm(cst, C_X * B + p))};
-    affine P[1] = {ld_affine(pts + ((size_t)VP_S * B + p) * 64)};
-    acc = glv_multiexp_dev<1>(k, P, tab, B, p);
-    acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
-    acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
-  }
-  // affine form with one inversion per workgroup; the identity (ZZZ = 0) comes back as 0 and stays (0, 0)
-  u256 zi = block_batch_inverse<FqInvOps>(live ? acc.ZZZ : u256_one(), inv_lds);
-  affine out = affine_inf();
-  if (live) {
-    out = xyzz_to_affine_with_inv(acc, zi);
-    st_affine(acc_aff + (size_t)p * 64, out);
-    if (host_out) st_affine(host_out + (size_t)p * 64, out);
-  }
-  if (host_txt) block_store_point_text(lds, out, host_txt, d.B);  // uniform branch: every thread of the block arrives
-}
-
-// Joint tables of the rounds, built before any challenge is known: for round r the 15 sums over the non-empty
-// subsets of {L_r, phi(L_r), R_r, phi(R_r)} as AFFINE points, rtab[(15 r + e - 1) * B + p] (64 B each).
+// Joint tables, built before any challenge is known: for a pair of the proof's points (P0, P1) the 15 sums over the
+// non-empty subsets of {P0, phi(P0), P1, phi(P1)} as AFFINE points, rtab[(15 t + e - 1) * B + p] (64 B each).
 // glv_split_pos leaves no signs, so the tables depend on the proof's points only: this kernel runs on the
-// side stream beside stage 1, off the host's critical path, and k_round adds table entries with mixed
-// additions (8M + 2S) instead of building an XYZZ table per round and using full additions (12M + 2S).
-// The 11 composite entries of every round are formed in XYZZ (rtx) and normalised with ONE inversion per
-// proof (Montgomery's trick over all 11 k entries; rpre holds the running products).
+// side stream off the host's critical path, and the chains add table entries with mixed additions (8M + 2S)
+// instead of building an XYZZ table per use and adding its entries with full additions (12M + 2S).
+// Tables 0..k-1 are the rounds' (L_r, R_r); table k is S alone (stage 1's x * S); tables k+1.. pair up the terms of
+// the t-polynomial check, V_0..V_{m-1}, T1, T2 (the last one holds a single point when m + 2 is odd, i.e. m = 1).
+// A table of a single point has the entries 1..3 only.
+// The composite entries are formed in XYZZ (rtx) and normalised with ONE inversion per proof (Montgomery's trick
+// over all composite entries; rpre holds the running products).
 __device__ __forceinline__ int composite_index(int e, int top) { return e - 2 - top; }  // 3,5,6,7,9..15 -> 0..10
 
+__host__ __device__ inline uint32_t vt_terms(const VDims& d) { return d.m + 2; }                    // V_j, T1, T2
+__host__ __device__ inline uint32_t vt_tables(const VDims& d) { return (vt_terms(d) + 1) / 2; }     // their pair tables
+__host__ __device__ inline uint32_t vt_first(const VDims& d) { return d.k + 1; }                    // index of the first
+__host__ __device__ inline uint32_t joint_tables(const VDims& d) { return d.k + 1 + vt_tables(d); }
+// point row of term j of the t-check's list
+__device__ __forceinline__ uint32_t vt_row(const VDims& d, uint32_t term) {
+  return term < d.m ? VP_L0 + 2 * d.k + term : (term == d.m ? VP_T1 : VP_T2);
+}
+// rows of the two points of table t; rb = -1: a single point
+__device__ __forceinline__ void joint_table_rows(const VDims& d, uint32_t t, int& ra, int& rb) {
+  if (t < d.k) {
+    ra = (int)(VP_L0 + t);
+    rb = (int)(VP_L0 + d.k + t);
+  } else if (t == d.k) {
+    ra = (int)VP_S;
+    rb = -1;
+  } else {
+    const uint32_t j = 2 * (t - d.k - 1);
+    ra = (int)vt_row(d, j);
+    rb = j + 1 < vt_terms(d) ? (int)vt_row(d, j + 1) : -1;
+  }
+}
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
-k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx /*[11 k][B]*/,
-               u256* __restrict__ rpre /*[11 k][B]*/, uint8_t* __restrict__ rtab /*[15 k][B][64]*/) {
+k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx /*[11 T][B]*/,
+               u256* __restrict__ rpre /*[11 T][B]*/, uint8_t* __restrict__ rtab /*[15 T][B][64]*/,
+               uint32_t t_lo, uint32_t t_hi, uint32_t t_skip /*tables t_lo <= t < t_hi except t_skip*/) {
   __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = p < d.B;
   const size_t B = d.B, ES = B * 64;  // stride between table entries of one proof
   u256 run = u256_one();
 #pragma unroll 1
-  for (uint32_t r = 0; live && r < d.k; r++) {
+  for (uint32_t r = t_lo; live && r < t_hi; r++) {
+    if (r == t_skip) continue;
     uint8_t* T = rtab + ((size_t)r * 15 * B + p) * 64;
-    affine L = ld_affine(pts + ((size_t)(VP_L0 + r) * B + p) * 64);
-    affine Rp = ld_affine(pts + ((size_t)(VP_L0 + d.k + r) * B + p) * 64);
+    int ra, rb;
+    joint_table_rows(d, r, ra, rb);
+    affine L = ld_affine(pts + ((size_t)ra * B + p) * 64);
     st_affine(T + 0 * ES, L);
     st_affine(T + 1 * ES, glv_phi(L));
-    st_affine(T + 3 * ES, Rp);
-    st_affine(T + 7 * ES, glv_phi(Rp));
+    if (rb >= 0) {
+      affine Rp = ld_affine(pts + ((size_t)rb * B + p) * 64);
+      st_affine(T + 3 * ES, Rp);
+      st_affine(T + 7 * ES, glv_phi(Rp));
+    }
+    const int e_end = rb >= 0 ? 16 : 4;
 #pragma unroll 1
-    for (int e = 3; e < 16; e++) {
+    for (int e = 3; e < e_end; e++) {
       int top = 31 - __builtin_clz((unsigned)e);
       int rest = e & ~(1 << top);
       if (rest == 0) continue;
@@ -452,10 +417,13 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
   u256 inv = block_batch_inverse<FqInvOps>(run, inv_lds);
   if (!live) return;
 #pragma unroll 1
-  for (uint32_t rr = d.k; rr-- > 0;) {
+  for (uint32_t rr = t_hi; rr-- > t_lo;) {
+    if (rr == t_skip) continue;
     uint8_t* T = rtab + ((size_t)rr * 15 * B + p) * 64;
+    int ra, rb;
+    joint_table_rows(d, rr, ra, rb);
 #pragma unroll 1
-    for (int e = 15; e >= 3; e--) {
+    for (int e = rb >= 0 ? 15 : 3; e >= 3; e--) {
       int top = 31 - __builtin_clz((unsigned)e);
       if ((e & ~(1 << top)) == 0) continue;
       size_t slot = ((size_t)rr * 11 + composite_index(e, top)) * B + p;
@@ -469,6 +437,41 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
       st_affine(T + (size_t)(e - 1) * ES, a);
     }
   }
+}
+
+// stage 1 tail: P = acc1 + x*S + A  -> affine (kept on device and exported).  x * S runs on S's joint table (table k of
+// k_round_tables, complete before this kernel is launched): a doubling and at most one mixed addition per bit.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_stage1_tail(VDims d, const uint8_t* __restrict__ pts /*[..][B][64]*/,
+                                                    const u256* __restrict__ cst, const xyzz* __restrict__ acc1,
+                                                    const uint8_t* __restrict__ rtab, uint8_t* __restrict__ acc_aff /*[B][64]*/,
+                                                    uint8_t* __restrict__ host_out /*pinned host copy, or null*/,
+                                                    uint8_t* __restrict__ host_txt /*pinned [B][2][80] decimal text, or null*/) {
+  __shared__ uint32_t lds[256 * 2 * DEC_REC_WORDS];
+  // the host waits for this kernel (it hashes P next): its waves take issue priority over the throughput
+  // kernels of other chunks that share the SIMDs
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ u256 inv_lds[BATCHINV_LDS];
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < d.B;
+  xyzz acc = xyzz_inf();
+  if (live) {
+    size_t B = d.B;
+    const u256 k[2] = {Fr::from_mont(ldm(cst, C_X * B + p)), u256_zero()};
+    const bool present[2] = {true, false};
+    const uint8_t* T = rtab + ((size_t)d.k * 15 * B + p) * 64;
+    acc = glv_tables_multiexp29<1>(k, present, [&](int, int e) { return ld_affine(T + (size_t)(e - 1) * B * 64); });
+    acc = xyzz_add(acc, ld_xyzz(&acc1[p]));
+    acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
+  }
+  // affine form with one inversion per workgroup; the identity (ZZZ = 0) comes back as 0 and stays (0, 0)
+  u256 zi = block_batch_inverse<FqInvOps>(live ? acc.ZZZ : u256_one(), inv_lds);
+  affine out = affine_inf();
+  if (live) {
+    out = xyzz_to_affine_with_inv(acc, zi);
+    st_affine(acc_aff + (size_t)p * 64, out);
+    if (host_out) st_affine(host_out + (size_t)p * 64, out);
+  }
+  if (host_txt) block_store_point_text(lds, out, host_txt, d.B);  // uniform branch: every thread of the block arrives
 }
 
 // one IPP round of mkChallenges: acc <- x^2 L + x^-2 R + acc  (Verifier.hs:47-50)
@@ -925,28 +928,84 @@ __global__ void __launch_bounds__(256) k_vprep_t(VDims d, const uint8_t* __restr
   st_u256(vs + ((size_t)(d.m + 1) * B + p) * 32, Fr::from_mont(Fr::neg(ldm(cst, C_X2 * B + p))));
 }
 
-// acc2 += sum of up to 2 variable-base terms per pass (terms j0, j0+1 of the E2 list:
-// V_0..V_{m-1}, T1, T2); the list length m + 2 is even for every power-of-two m >= 2 and 3 for m = 1.
+// acc2 += the terms of NT joint tables of the t-check's list (V_0..V_{m-1}, T1, T2 in pairs, tables vt_first + t0 ..
+// of k_round_tables): up to four terms on one doubling chain.
 template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_var_terms(VDims d, uint32_t j0, const uint8_t* __restrict__ pts,
-                                                  const uint8_t* __restrict__ vs, xyzz* __restrict__ tab,
-                                                  xyzz* __restrict__ acc2) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_var_terms(VDims d, uint32_t t0, const uint8_t* __restrict__ vs,
+                                                  const uint8_t* __restrict__ rtab, xyzz* __restrict__ acc2) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   size_t B = d.B;
-  u256 k[NT];
-  affine P[NT];
+  u256 k[2 * NT];
+  bool present[2 * NT];
 #pragma unroll
-  for (int j = 0; j < NT; j++) {
-    uint32_t term = j0 + j;
-    k[j] = ld_u256(vs + ((size_t)term * B + p) * 32);
-    // point row: V_j for term < m, then T1, T2
-    uint32_t row = term < d.m ? VP_L0 + 2 * d.k + term : (term == d.m ? VP_T1 : VP_T2);
-    P[j] = ld_affine(pts + ((size_t)row * B + p) * 64);
+  for (int j = 0; j < 2 * NT; j++) {
+    const uint32_t term = 2 * t0 + j;
+    present[j] = term < vt_terms(d);
+    k[j] = present[j] ? ld_u256(vs + ((size_t)term * B + p) * 32) : u256_zero();
   }
-  xyzz acc = glv_multiexp_dev<NT>(k, P, tab, B, p);
+  const uint8_t* T = rtab + ((size_t)(vt_first(d) + t0) * 15 * B + p) * 64;
+  xyzz acc = glv_tables_multiexp29<NT>(k, present, [&](int t, int e) {
+    return ld_affine(T + ((size_t)t * 15 + (size_t)(e - 1)) * B * 64);
+  });
   acc = xyzz_add(acc, ld_xyzz(&acc2[p]));
   st_xyzz(&acc2[p], acc);
+}
+
+// ---- the transcript on the device (fsdev.h): challenges formed where the proofs and the running commitment live -----
+// y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86) of every proof, from the loaded proof
+// alone; chal[4][B][32] is what vbatch_begin_async otherwise takes from the host.  msg: FS_MSG_WORDS x B words.
+__global__ void __launch_bounds__(256) k_fs_initial(VDims d, int style, const uint8_t* __restrict__ sc, const uint8_t* __restrict__ pts,
+                                                   uint32_t* __restrict__ msg, uint8_t* __restrict__ chal) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  const size_t B = d.B;
+  auto pt = [&](FsMsg& m, uint32_t row) {
+    const affine a = ld_affine(pts + ((size_t)row * B + p) * 64);
+    fs_put_point(m, style, a.x, a.y);
+  };
+  FsMsg m = fs_open(msg + p, B);
+  pt(m, VP_A);
+  pt(m, VP_S);
+  const FsMark as = fs_mark(m);
+  const u256 y = fs_finish_fr(m);  // shamirY: show _r <> A <> S   (Utils.hs:145-148)
+  fs_rewind(m, as);
+  fs_put_fr(m, style, y);
+  const u256 z = fs_finish_fr(m);  // shamirZ: ... <> show y   (Utils.hs:150-153)
+  fs_rewind(m, as);
+  pt(m, VP_T1);
+  pt(m, VP_T2);
+  fs_put_fr(m, style, y);
+  fs_put_fr(m, style, z);
+  const u256 x = fs_finish_fr(m);  // shamirX: show _r <> A <> S <> T1 <> T2 <> show y <> show z   (Utils.hs:155-165)
+  FsMsg mu = fs_open(msg + p, B);
+  fs_put_fr(mu, style, ld_u256(sc + ((size_t)VS_TAU * B + p) * 32));
+  fs_put_fr(mu, style, ld_u256(sc + ((size_t)VS_MU * B + p) * 32));
+  fs_put_fr(mu, style, ld_u256(sc + ((size_t)VS_T * B + p) * 32));
+  const u256 u = fs_finish_fr(mu);  // shamirU: show _r <> show tBlinding <> show mu <> show t   (Utils.hs:172-174)
+  st_u256(chal + ((size_t)0 * B + p) * 32, y);
+  st_u256(chal + ((size_t)1 * B + p) * 32, z);
+  st_u256(chal + ((size_t)2 * B + p) * 32, x);
+  st_u256(chal + ((size_t)3 * B + p) * 32, u);
+}
+
+// x_r = shamirX' acc L_r R_r = oracle (show _r <> L_r <> R_r <> acc)  (mkChallenges, InnerProductProof/Verifier.hs:44-53;
+// Utils.hs:167-170), acc the running commitment the previous kernel left in acc_aff
+__global__ void __launch_bounds__(256) k_fs_round(VDims d, uint32_t round, int style, const uint8_t* __restrict__ pts,
+                                                 const uint8_t* __restrict__ acc_aff, uint32_t* __restrict__ msg,
+                                                 uint8_t* __restrict__ xk /*[B][32]*/) {
+  __builtin_amdgcn_s_setprio(3);
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.B) return;
+  const size_t B = d.B;
+  FsMsg m = fs_open(msg + p, B);
+  const affine L = ld_affine(pts + ((size_t)(VP_L0 + round) * B + p) * 64);
+  const affine Rr = ld_affine(pts + ((size_t)(VP_L0 + d.k + round) * B + p) * 64);
+  const affine acc = ld_affine(acc_aff + (size_t)p * 64);
+  fs_put_point(m, style, L.x, L.y);
+  fs_put_point(m, style, Rr.x, Rr.y);
+  fs_put_point(m, style, acc.x, acc.y);
+  st_u256(xk + (size_t)p * 32, fs_finish_fr(m));
 }
 
 // Input validation at load time: bad[p] = 1 when proof p holds a point that is neither O nor a canonically encoded
@@ -1043,18 +1102,17 @@ static inline void launch_tcheck(bp_vbatch* vb, hipStream_t strm) {
   size_t B = d.B;
   hipLaunchKernelGGL(k_vprep_t, VB_GRID_ON(B, strm), d, vb->sc, vb->cst, vb->zpow, vb->dig3b, vb->vs);
   launch_fixed(vb, B, vb->nt3b, 1u, vb->dig3b, vb->tb3b, vb->acc2, strm);
-  uint32_t nv = d.m + 2;
-  uint32_t j = 0;
   if (vb->split) {
     hipLaunchKernelGGL(k_tcheck_bits, dim3(d.B), dim3(256), 0, strm, d, vb->vs, vb->sh, vb->acc2);
     return;
   }
-  if (nv & 1u) {  // m = 1: three terms, one pass of three
-    hipLaunchKernelGGL(k_var_terms<3>, VB_GRID_ON(B, strm), d, 0u, vb->pts, vb->vs, vb->vtab2, vb->acc2);
-    j = 3;
+  const uint32_t nt = vt_tables(d);
+  for (uint32_t t = 0; t < nt; t += 2) {
+    if (t + 1 < nt)
+      hipLaunchKernelGGL(k_var_terms<2>, VB_GRID_ON(B, strm), d, t, vb->vs, vb->rtab, vb->acc2);
+    else
+      hipLaunchKernelGGL(k_var_terms<1>, VB_GRID_ON(B, strm), d, t, vb->vs, vb->rtab, vb->acc2);
   }
-  for (; j < nv; j += 2)
-    hipLaunchKernelGGL(k_var_terms<2>, VB_GRID_ON(B, strm), d, j, vb->pts, vb->vs, vb->vtab2, vb->acc2);
 }
 
 int vbatch_load_async(bp_vbatch* vb, const uint8_t* scalars, const uint8_t* points) {
@@ -1089,7 +1147,7 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
   }
   VDims d = vb->d;
   size_t B = d.B;
-  if ((d.k == 0 && !vb->split) || vb->tab_pending) return BP_OK;
+  if (vb->tab_pending) return BP_OK;
   if (vb->t_pending) {  // a previous pass's side work
     BP_TRY(hipStreamSynchronize(vb->aux));
     vb->t_pending = false;
@@ -1100,11 +1158,12 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
     int rc = ipp_bit_tables(ctx, vb->pts + (size_t)VP_S * B * 64, cnt, vb->sh, vb->aux);
     if (rc != BP_OK) return rc;
   } else {
-    if (lr_text && vb->direct_host) {
+    if (lr_text && vb->direct_host && d.k) {
       size_t cnt = (size_t)2 * d.k * B * 2;
       hipLaunchKernelGGL(k_dec_numbers, VB_GRID_ON(cnt, vb->aux), vb->pts + (size_t)VP_L0 * B * 64, (uint32_t)cnt, lr_text);
     }
-    hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab);
+    // every joint table but S's, which stage 1 needs first and builds on its own stream
+    hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, vb->aux), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, 0u, joint_tables(d), d.k);
   }
   BP_TRY(hipGetLastError());
   vb->tab_pending = true;
@@ -1169,6 +1228,11 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
     vb->begun_complete = false;
     return BP_OK;
   }
+  static const int pair_env = getenv("BP_ROUND_PAIR") ? atoi(getenv("BP_ROUND_PAIR")) : -1;
+  const bool tail_pair = pair_env < 0 ? B <= 8192 : pair_env != 0;
+  // S's joint table (one composite entry), in front of the stage that uses it on the same stream
+  if (!tail_pair)
+    hipLaunchKernelGGL(k_round_tables, VB_GRID(B), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, d.k, d.k + 1, 0xFFFFFFFFu);
   hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, chal, vb->cst, vb->ypowinv, vb->zpow, true);
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   prof_begin(vb, 0, vb->nt1);
@@ -1178,13 +1242,13 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
   // other (measured: benchmarks/concurrency_test3.hip); with pinned outputs the kernel stores its
   // result to host memory itself.
   // chunks of at most 8,192 proofs: the chain of x*S on pairs of lanes, as in the rounds (BP_ROUND_PAIR)
-  static const int pair_env = getenv("BP_ROUND_PAIR") ? atoi(getenv("BP_ROUND_PAIR")) : -1;
-  if (pair_env < 0 ? B <= 8192 : pair_env != 0)
+  if (tail_pair)
     hipLaunchKernelGGL(k_stage1_tail_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, vb->stream, d, vb->pts,
                        vb->cst, vb->acc1, (uint8_t*)vb->vtab, vb->acc_aff, direct, vb->direct_host ? out_text : nullptr);
-  else
-    hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->vtab, vb->acc_aff, direct,
+  else {
+    hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->rtab, vb->acc_aff, direct,
                        vb->direct_host ? out_text : nullptr);
+  }
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(out_commitment, vb->acc_aff, B * 64, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 2;
@@ -1285,6 +1349,80 @@ int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts) {
   BP_TRY(hipGetLastError());
   if (!direct) BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, vb->stream));
   vb->stage = 1;  // may be begun again with the same loaded proofs
+  return BP_OK;
+}
+
+// A whole pass with the transcript on the device: every kernel of the pass goes onto the batch's stream in order, the
+// challenges pass from kernel to kernel in HBM and the host only collects the verdicts (vbatch_wait, then `verdicts`
+// holds them: pinned memory the last kernel stores to, or the target of a copy on the same stream).
+int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->stage < 1 || vb->split) {
+    ctx->err = vb->split ? "device transcript: not for the latency path" : "device transcript before bp_vbatch_load";
+    return BP_ERR_STATE;
+  }
+  if (vb->epoch != ctx->gen_epoch) {
+    ctx->err = "the context's generators were replaced after this batch object was created: create a new one";
+    return BP_ERR_STATE;
+  }
+  if (vb->t_pending || vb->tab_pending) {  // side work of an earlier pass of the host-transcript form
+    BP_TRY(hipStreamSynchronize(vb->aux));
+    vb->t_pending = vb->tab_pending = false;
+  }
+  const VDims d = vb->d;
+  const size_t B = d.B;
+  const int style = ctx->show_style;
+  hipStream_t strm = vb->stream;
+  static const int pair_env = getenv("BP_ROUND_PAIR") ? atoi(getenv("BP_ROUND_PAIR")) : -1;
+  const bool pair = pair_env < 0 ? B <= 8192 : pair_env != 0;
+  // The side stream carries what the main chain does not wait for: every joint table but S's (wanted by round 0 and by
+  // the t-check) and the t-polynomial check (wants y, z, x: k_vprep0's constants).  Its chains run beside the main
+  // stream's, a second wave on the SIMDs.  BP_FS_SIDE=0 keeps everything on one stream.
+  static const bool side_env = !(getenv("BP_FS_SIDE") && atoi(getenv("BP_FS_SIDE")) == 0);
+  const bool side = side_env && vb->aux != strm;
+  hipStream_t sd = side ? vb->aux : strm;
+  hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, sd), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, 0u, joint_tables(d), d.k);
+  if (side) BP_TRY(hipEventRecord(vb->fs_ev[1], sd));
+  hipLaunchKernelGGL(k_fs_initial, VB_GRID(B), d, style, vb->sc, vb->pts, vb->fsmsg, vb->chal);
+  hipLaunchKernelGGL(k_round_tables, VB_GRID(B), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, d.k, d.k + 1, 0xFFFFFFFFu);
+  hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow, true);
+  if (side) {
+    BP_TRY(hipEventRecord(vb->fs_ev[0], strm));
+    BP_TRY(hipStreamWaitEvent(sd, vb->fs_ev[0], 0));
+  }
+  launch_tcheck(vb, sd);
+  if (side) BP_TRY(hipEventRecord(vb->fs_ev[2], sd));
+  hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
+  const uint32_t lpp = vbatch_lpp(d.B);
+  launch_fixed(vb, B * lpp, vb->nt1, lpp, vb->dig1, vb->tb1, vb->acc1);
+  if (pair)
+    hipLaunchKernelGGL(k_stage1_tail_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, strm, d, vb->pts,
+                       vb->cst, vb->acc1, (uint8_t*)vb->vtab, vb->acc_aff, (uint8_t*)nullptr, (uint8_t*)nullptr);
+  else
+    hipLaunchKernelGGL(k_stage1_tail, VB_GRID(B), d, vb->pts, vb->cst, vb->acc1, vb->rtab, vb->acc_aff, (uint8_t*)nullptr,
+                       (uint8_t*)nullptr);
+  // the rounds read the side stream's tables
+  if (side) BP_TRY(hipStreamWaitEvent(strm, vb->fs_ev[1], 0));
+  for (uint32_t r = 0; r < d.k; r++) {
+    hipLaunchKernelGGL(k_fs_round, VB_GRID(B), d, r, style, vb->pts, vb->acc_aff, vb->fsmsg, vb->xk);
+    if (pair)
+      hipLaunchKernelGGL(k_round_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, strm, d, r, vb->xk,
+                         vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, (uint8_t*)nullptr, (uint8_t*)nullptr);
+    else
+      hipLaunchKernelGGL(k_round<false>, VB_GRID(B), d, r, vb->xk, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff,
+                         (uint8_t*)nullptr, (uint8_t*)nullptr);
+  }
+  hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xk_m, vb->xkinv_m, vb->cst, vb->stab);
+  hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->stab, vb->dig3a);
+  launch_fixed(vb, B * lpp, vb->nt3a, lpp, vb->dig3a, vb->tb3a, vb->acc1);
+  if (side) BP_TRY(hipStreamWaitEvent(strm, vb->fs_ev[2], 0));  // acc2 of the t-check
+  uint8_t* direct = vb->direct_host ? verdicts : nullptr;
+  hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, (const xyzz*)nullptr, vb->bad, vb->verdict,
+                     direct);
+  BP_TRY(hipGetLastError());
+  if (!direct) BP_TRY(hipMemcpyAsync(verdicts, vb->verdict, B, hipMemcpyDeviceToHost, strm));
+  vb->stage = 1;
+  vb->begun_complete = false;
   return BP_OK;
 }
 
@@ -1401,11 +1539,11 @@ int bp::vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batc
     vb->tb3b = c.take<uint32_t>(vb->nt3b);
     vb->acc1 = c.take<xyzz>(B);
     vb->acc2 = c.take<xyzz>(B);
-    vb->vtab = c.take<xyzz>((size_t)VT_ENTRIES * B);
-    vb->vtab2 = c.take<xyzz>((size_t)VT_ENTRIES * B);
-    vb->rtx = c.take<xyzz>((size_t)11 * (d.k ? d.k : 1) * B);
-    vb->rpre = c.take<u256>((size_t)11 * (d.k ? d.k : 1) * B);
-    vb->rtab = c.take<uint8_t>((size_t)15 * (d.k ? d.k : 1) * B * 64);
+    vb->vtab = c.take<xyzz>(B);  // S, phi(S) of k_stage1_tail_pair (128 bytes per proof)
+    vb->fsmsg = c.take<uint32_t>((size_t)FS_MSG_WORDS * B);  // the device transcript's message buffers
+    vb->rtx = c.take<xyzz>((size_t)11 * joint_tables(d) * B);
+    vb->rpre = c.take<u256>((size_t)11 * joint_tables(d) * B);
+    vb->rtab = c.take<uint8_t>((size_t)15 * joint_tables(d) * B * 64);
     {
       const size_t sb = B <= split_max ? B : 1;
       vb->sh = c.take<xyzz>((size_t)(vb->npts - VP_S) * sb * GLV_LANE_BITS);  // bit tables of rows S.. (16 KB a point)
@@ -1429,6 +1567,10 @@ int bp::vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batc
     vb->ev[s2][0] = vb->ev[s2][1] = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][0]);
     if (e == hipSuccess) e = hipEventCreate(&vb->ev[s2][1]);
+  }
+  for (int s2 = 0; s2 < 3; s2++) {
+    vb->fs_ev[s2] = nullptr;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&vb->fs_ev[s2], hipEventDisableTiming);
   }
   vb->hx = nullptr;
   vb->hinv = nullptr;
@@ -1492,6 +1634,8 @@ void bp_vbatch_destroy(bp_vbatch* vb) {
   for (int s = 0; s < 3; s++)
     for (int j = 0; j < 2; j++)
       if (vb->ev[s][j]) (void)hipEventDestroy(vb->ev[s][j]);
+  for (int s = 0; s < 3; s++)
+    if (vb->fs_ev[s]) (void)hipEventDestroy(vb->fs_ev[s]);
   if (vb->done) (void)hipEventDestroy(vb->done);
   delete vb;
 }

@@ -214,6 +214,25 @@ extern "C" void hs_glv_pair_tab29(const uint8_t* ks, const uint8_t* ps, uint8_t*
   xyzz r = glv_pair_multiexp_tab29(ld(ks), ld(ks + 32), [&](int e) { return tab[e]; });
   sta(out, xyzz_to_affine(r));
 }
+// two joint tables on one doubling chain (glv_tables_multiexp29): ks = 4 scalars, present = 4 flags, ps = 4 points; an
+// absent term's point is not read (its table half is left as the identity)
+extern "C" void hs_glv_tables29(int nt, const uint8_t* ks, const uint8_t* present, const uint8_t* ps, uint8_t* out) {
+  affine tab[2][16];
+  for (int t = 0; t < nt; t++)
+    glv_pair_table_local(lda(ps + (2 * t) * 64), present[2 * t + 1] ? lda(ps + (2 * t + 1) * 64) : affine_inf(), tab[t]);
+  auto load = [&](int t, int e) { return tab[t][e]; };
+  xyzz r;
+  if (nt == 1) {
+    const u256 k[2] = {ld(ks), ld(ks + 32)};
+    const bool pr[2] = {present[0] != 0, present[1] != 0};
+    r = glv_tables_multiexp29<1>(k, pr, load);
+  } else {
+    const u256 k[4] = {ld(ks), ld(ks + 32), ld(ks + 64), ld(ks + 96)};
+    const bool pr[4] = {present[0] != 0, present[1] != 0, present[2] != 0, present[3] != 0};
+    r = glv_tables_multiexp29<2>(k, pr, load);
+  }
+  sta(out, xyzz_to_affine(r));
+}
 // sum of n points by full XYZZ additions on lazy limbs (every point enters as k_i * P_i with small k_i so that Z != 1)
 extern "C" void hs_add29_chain(const uint8_t* pts, size_t n, uint8_t* out) {
   xyzz29 acc = xyzz29_inf();
@@ -228,6 +247,44 @@ extern "C" void hs_dbl29_chain(const uint8_t* pt, int n, uint8_t* out) {
   xyzz29 acc = xyzz29_from_affine(lda(pt), false);
   for (int i = 0; i < n; i++) acc = xyzz29_dbl(acc);
   sta(out, xyzz_to_affine(xyzz29_to(acc)));
+}
+
+// ---- device transcript (fsdev.h): the challenges of the range-proof verifier as the kernels form them ----
+#include "../../bulletproofs_amd/csrc/fsdev.h"
+// which: 0 shamirY (A,S)  1 shamirZ (A,S | y)  2 shamirX (A,S,T1,T2 | y,z)  3 shamirU (| tau,mu,t)  4 shamirX' (L,R,acc)
+// pts: up to 4 points (64 B each), scs: up to 3 scalars; stride: words between consecutive words of the message buffer
+extern "C" void hs_fs_challenge(int style, int which, const uint8_t* pts, const uint8_t* scs, size_t stride, uint8_t* out) {
+  std::vector<uint32_t> buf((size_t)FS_MSG_WORDS * stride, 0xA5A5A5A5u);
+  FsMsg m = fs_open(buf.data(), stride);
+  auto pt = [&](int i) { fs_put_point(m, style, ld(pts + i * 64), ld(pts + i * 64 + 32)); };
+  auto sc = [&](int i) { fs_put_fr(m, style, ld(scs + i * 32)); };
+  if (which == 0) { pt(0); pt(1); }
+  if (which == 1) { pt(0); pt(1); sc(0); }
+  if (which == 2) { pt(0); pt(1); pt(2); pt(3); sc(0); sc(1); }
+  if (which == 3) { sc(0); sc(1); sc(2); }
+  if (which == 4) { pt(0); pt(1); pt(2); }
+  st(out, fs_finish_fr(m));
+}
+// y, z, x from one buffer with a rewind to the shared opening text, as k_fs_initial does
+extern "C" void hs_fs_yzx(int style, const uint8_t* pts, size_t stride, uint8_t* out3) {
+  std::vector<uint32_t> buf((size_t)FS_MSG_WORDS * stride, 0);
+  FsMsg m = fs_open(buf.data(), stride);
+  fs_put_point(m, style, ld(pts), ld(pts + 32));
+  fs_put_point(m, style, ld(pts + 64), ld(pts + 96));
+  const FsMark as = fs_mark(m);
+  const u256 y = fs_finish_fr(m);
+  fs_rewind(m, as);
+  fs_put_fr(m, style, y);
+  const u256 z = fs_finish_fr(m);
+  fs_rewind(m, as);
+  fs_put_point(m, style, ld(pts + 128), ld(pts + 160));
+  fs_put_point(m, style, ld(pts + 192), ld(pts + 224));
+  fs_put_fr(m, style, y);
+  fs_put_fr(m, style, z);
+  const u256 x = fs_finish_fr(m);
+  st(out3, y);
+  st(out3 + 32, z);
+  st(out3 + 64, x);
 }
 
 // ---- device decimal formatter (dec.h): 80-byte record of a 32-byte LE integer ----

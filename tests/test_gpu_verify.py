@@ -117,6 +117,32 @@ def test_state_machine_vs_oracle(eng_gens, n, m):
     assert got == exp
 
 
+@pytest.mark.parametrize("n,m,copies", [(1, 1, 13), (4, 2, 13), (2, 4, 13), (2, 3, 13), (2, 8, 13), (1, 1, 1100),
+                                        (2, 2, 1100)])
+def test_throughput_kernels_with_aggregated_proofs(eng_gens, n, m, copies):
+    """Above 96 proofs the state machine leaves the one-lane-per-bit path: x * S and the t-check's V_j, T1, T2 run
+    on the joint tables of k_round_tables (verify.hip), the t-check with one or two tables per chain (m + 2 terms in
+    pairs: m = 1 a pair and a single point, m = 4 three pairs in two passes); above 8,192 the stage-1 tail is the
+    one-lane-per-proof kernel.  n * m = 1 has no rounds at all (tables of S and the t-check only).  Every stage's
+    accumulator and the verdicts against the oracle, honest and corrupted proofs mixed."""
+    rng = random.Random(3000 + 10 * n + m)
+    m2 = 2 ** o.log2_ceil(m)
+    proofs, vcs = [], []
+    for _ in range(3):
+        vs = [(rng.randrange(0, 2**n), rng.randrange(1, R)) for _ in range(m)]
+        proofs.append(o.mrp_generate_proof(2**n, vs, *o.draw_blinders(rng, n * m2)))
+        vcs.append([o.commit(v, b) for v, b in vs])
+    bad = [mutate(rng, proofs[i % 3], vcs[i % 3]) for i in range(5)]
+    all_p = proofs + [b[0] for b in bad]
+    all_v = vcs + [b[1] for b in bad]
+    nb = len(all_p)
+    exp = [o.mrp_verify_proof(2**n, v, p) for p, v in zip(all_p, all_v)]
+    assert exp[:3] == [True] * 3
+    got = run_batch(eng_gens, n, m2, all_p * copies, all_v * copies,
+                    check_trace=list(range(nb)) + list(range(nb * (copies - 1), nb * copies)))
+    assert got == exp * copies
+
+
 def degenerate_lr(pr, kind, r):
     """A copy of the proof whose round-r commitments hit the group law's special cases."""
     ipp = dict(pr["productProof"])

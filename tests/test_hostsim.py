@@ -150,6 +150,41 @@ def test_device_decimal_records(hs):
             assert out1.raw[:n1] == out2.raw[:n2]
 
 
+def test_device_transcript_matches_the_oracle(hs):
+    """fsdev.h (the challenges formed on the GPU: verify.hip k_fs_initial / k_fs_round): `show` text, SHA-256 and the
+    digest as a scalar equal the oracle's shamirY / Z / X / U / X' (Utils.hs:145-174) in both `show` styles, for
+    random and edge inputs (O, small coordinates with short decimal text, digests >= r are covered by the reduction
+    test below), with the message buffer contiguous or strided as on the device."""
+    rng = random.Random(91)
+    G = o.GEN
+    pts = [o.point_mul(G, rng.randrange(1, R)) for _ in range(6)] + [None, (1, 2), (0, 5), (10**9, 10**18), (P - 1, P - 1)]
+    scs = [0, 1, 9, 10, 10**76, 10**77, R - 1, R - 2, 2**255] + [rng.randrange(R) for _ in range(6)]
+    old = o.SHOW_STYLE
+    try:
+        for style, name in ((0, "derived"), (1, "plain")):
+            o.SHOW_STYLE = name
+            for it in range(40):
+                p4 = [rng.choice(pts) for _ in range(4)]
+                s3 = [rng.choice(scs) for _ in range(3)]
+                stride = rng.choice([1, 1, 3, 64])
+                exp = [o.shamir_y(p4[0], p4[1]), o.shamir_z(p4[0], p4[1], s3[0]),
+                       o.shamir_x(p4[0], p4[1], p4[2], p4[3], s3[0], s3[1]), o.shamir_u(s3[0], s3[1], s3[2]),
+                       o.shamir_x_prime(p4[2], p4[0], p4[1])]
+                for which in range(5):
+                    out = ctypes.create_string_buffer(32)
+                    hs.hs_fs_challenge(style, which, b"".join(pb(q) for q in p4), b"".join(b(x) for x in s3),
+                                       ctypes.c_size_t(stride), out)
+                    assert int.from_bytes(out.raw, "little") == exp[which], (style, which, it)
+                out3 = ctypes.create_string_buffer(96)
+                hs.hs_fs_yzx(style, b"".join(pb(q) for q in p4), ctypes.c_size_t(stride), out3)
+                y = o.shamir_y(p4[0], p4[1])
+                z = o.shamir_z(p4[0], p4[1], y)
+                x = o.shamir_x(p4[0], p4[1], p4[2], p4[3], y, z)
+                assert [int.from_bytes(out3.raw[32 * i:32 * i + 32], "little") for i in range(3)] == [y, z, x]
+    finally:
+        o.SHOW_STYLE = old
+
+
 LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
 
 
@@ -185,6 +220,32 @@ def test_glv_positive_split_and_pair_table(hs):
         assert dp(out.raw) == o.point_mul(A, 2**n % R)
     hs.hs_dbl29_chain(pb(None), 3, out)
     assert dp(out.raw) is None
+
+
+def test_two_joint_tables_on_one_chain(hs):
+    """glv.h glv_tables_multiexp29 (verify.hip k_stage1_tail, k_var_terms): one or two sign-free joint tables on one
+    doubling chain, the second point of a table absent (a single-point table has the entries 1..3 only), against
+    the oracle's sum; identity, equal and opposite points included."""
+    rng = random.Random(83)
+    G = o.GEN
+    A, C, D, E = (o.point_mul(G, rng.randrange(1, R)) for _ in range(4))
+    edge = [0, 1, 2, R - 1, LAMBDA, R - LAMBDA, 2**128, 2**255]
+    cases = []
+    for pts in ([A, C, D, E], [A, A, o.point_neg(A), A], [None, C, D, None], [A, o.point_mul(A, LAMBDA), C, C]):
+        for present in ([1, 1, 1, 1], [1, 1, 1, 0], [1, 0, 1, 0], [1, 0, 1, 1]):
+            for _ in range(3):
+                cases.append((2, [rng.choice(edge + [rng.randrange(R)] * 4) for _ in range(4)], present, pts))
+        for present in ([1, 0], [1, 1]):
+            for _ in range(3):
+                cases.append((1, [rng.choice(edge + [rng.randrange(R)] * 4) for _ in range(2)], present, pts[:2]))
+    for nt, ks, present, pts in cases:
+        out = ctypes.create_string_buffer(64)
+        hs.hs_glv_tables29(nt, b"".join(b(k) for k in ks), bytes(present), b"".join(pb(q) for q in pts), out)
+        exp = None
+        for k, pr, q in zip(ks, present, pts):
+            if pr:
+                exp = o.point_add(exp, o.point_mul(q, k))
+        assert dp(out.raw) == exp, (nt, ks, present)
 
 
 def test_glv_bit_lanes(hs):
