@@ -376,6 +376,7 @@ def main():
     ap.add_argument("--msm-min-logn", type=int, default=16)
     ap.add_argument("--extras", type=int, default=1, help="single-proof configs and API-inclusive rates at N = 1")
     a = ap.parse_args()
+    fs_device = os.environ.get("BP_FS_DEVICE", "1") != "0"   # the library's switch: transcript on the GPU (default)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -477,8 +478,9 @@ def main():
                                               "(creates and caches the job on the context), then a second call"))
     # Two jobs in flight (bp_vjob_submit / bp_vjob_wait): what a serving loop over a stream of 65,536-proof batches gets.
     # The headline above stays the synchronous step; this rate is reported beside it.  The hardware runs four of the
-    # library's streams side by side, so two jobs in flight take TWO chunks each (four kernels of twice the width):
-    # 21.8 ms per pass against 24.1 ms with four chunks each (benchmarks/pipe_sweep.sh).
+    # library's streams side by side.  With the transcript on the device a job is one chunk (the library's default);
+    # with the host transcript (BP_FS_DEVICE=0) two jobs in flight want TWO chunks each: 21.8 ms per pass against
+    # 24.1 ms with four (benchmarks/pipe_sweep.sh) - pass --pipe-chunks 2 there.
     pipelined = None
     if a.extras:
         pj = [eng.vjob(n_bits, 1, B, a.pipe_chunks, host_threads) for _ in range(2)]
@@ -505,10 +507,10 @@ def main():
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             dp = float(tp.item())
         pipelined = dict(value=total * npass / dp, unit="verifies/s", passes=npass, ms_per_pass=dp / npass * 1e3,
-                         chunks_per_job=a.pipe_chunks,
-                         what="two jobs of %d proofs per GPU in flight on one context (bp_vjob_submit / bp_vjob_wait), "
-                              "%d chunks per job: the latency-bound rounds of one pass run beside the wide kernels of "
-                              "the other; every verdict checked" % (B, a.pipe_chunks))
+                         chunks_per_job=a.pipe_chunks or (1 if fs_device else 4),
+                         what="two jobs of %d proofs per GPU in flight on one context (bp_vjob_submit / bp_vjob_wait): "
+                              "the latency-bound rounds of one pass run beside the wide kernels of the other; every "
+                              "verdict checked" % B)
         for j in pj:
             j.close()
     if dist is not None:
@@ -567,14 +569,17 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE.json configs[3]: batch verification of %d independent %d-bit range proofs "
-                            "(m=1)%s, 1%% corrupted, per-proof verdicts checked; host Fiat-Shamir hashing "
+                            "(m=1)%s, 1%% corrupted, per-proof verdicts checked; the Fiat-Shamir transcript (%s) "
                             "inside the timed region; proofs resident in HBM + pinned host memory when the clock starts"
                             % (total, n_bits, " split over %d GPUs" % world if scaling == "strong" and world > 1 else
-                               (" per GPU x %d GPUs" % world if world > 1 else "")),
+                               (" per GPU x %d GPUs" % world if world > 1 else ""),
+                               "text, SHA-256 and challenges formed on the GPU" if fs_device else
+                               "hashed by the host's threads between the kernels"),
+                "transcript": "device" if fs_device else "host",
                 "proofs_total": total, "proofs_per_gpu": B, "bits": n_bits, "m": 1,
                 "host_threads": host_threads, "usable_cores": bpdist.usable_cores(), "ranks_on_host": local_world,
                 "pinned_cores": len(pinned) if pinned else None,
-                "chunks": a.chunks or (4 if B >= 16384 else (2 if B >= 4096 else 1)),
+                "chunks": a.chunks or (1 if fs_device else (4 if B >= 16384 else (2 if B >= 4096 else 1))),
                 "proofgen_s": gen_s,
                 "hw_queues_env": hwq, "stream_pool": pool, "concurrent_streams": conc,
             },
@@ -588,8 +593,9 @@ def main():
                 "achieved": ach, "peak": PEAK_TMAD, "unit": "Tmad/s", "frac": ach / PEAK_TMAD,
                 "launches": fixed_calls, "avg_launch_ms": fixed_ms / fixed_calls,
                 "algorithmic": "mixed adds x 10 modmul x 136 mad (8-limb Montgomery accounting); "
-                               "the kernel itself spends 74 v_mad_u64_u32 per modmul (pseudo-Mersenne fold)",
-                "executed_mad_frac_of_peak": ach * 74.0 / 136.0 / PEAK_TMAD,
+                               "the kernel itself executes 985 v_mad_u64_u32 (and ~650 other VALU instructions) per "
+                               "mixed addition on nine 29-bit limbs with the pseudo-Mersenne fold",
+                "executed_mad_frac_of_peak": ach * 985.0 / 1360.0 / PEAK_TMAD,
                 "traffic": None,
             }
             if iso and iso[1]:

@@ -356,6 +356,10 @@ class Engine:
         self._check(self.lib.bp_ctx_set_generators(self.h, enc_points(gs), enc_points(hs), enc_point(h), n),
                     "bp_ctx_set_generators")
 
+    def set_show_style(self, style):
+        """0: derived Show ("A (P x) (P y)", "P s"), 1: plain ("A x y", "s") - the text the transcript hashes."""
+        self._check(self.lib.bp_ctx_set_show_style(self.h, style), "bp_ctx_set_show_style")
+
     def vbatch(self, n_bits, m, batch):
         return VBatch(self, n_bits, m, batch)
 

@@ -109,6 +109,17 @@ BP_HD affine glv_phi(const affine& p) {
   return r;
 }
 
+// P + phi(P) = -phi^2(P) = (beta^2 x, -y): the three images of P under the endomorphism add up to O (1 + beta + beta^2 = 0
+// puts them on one line y = const), so this entry of a joint table costs one product
+BP_HD affine glv_p_plus_phi(const affine& p) {
+  const uint32_t BETA2[8] = {0x8E6AFA40u, 0x3EC693D6u, 0xED0A766Au, 0x630FB68Au, 0x53CBCB16u, 0x919BB861u, 0x9A83F8EFu, 0x851695D4u};
+  if (affine_is_inf(p)) return affine_inf();
+  affine r;
+  r.x = fq_mul(p.x, glv_const(BETA2));
+  r.y = fq_neg(p.y);
+  return r;
+}
+
 // 129-bit magnitudes as a left-aligned 160-bit shift register: top bit first
 struct BitReg {
   uint32_t w[5];

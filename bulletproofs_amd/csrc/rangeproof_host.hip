@@ -122,10 +122,11 @@ int default_threads() {
   return t > 16 ? 16 : t;
 }
 
-// BP_FS_DEVICE=0 keeps the Fiat-Shamir transcript on the host for every batch size
+// BP_FS_DEVICE=0 keeps the Fiat-Shamir transcript on the host for every batch size.  Read when a job is created (the
+// job keeps its form), so one process can hold jobs of both forms.
 bool fs_device_enabled() {
-  static const bool on = !(getenv("BP_FS_DEVICE") && atoi(getenv("BP_FS_DEVICE")) == 0);
-  return on;
+  const char* e = getenv("BP_FS_DEVICE");
+  return !(e && atoi(e) == 0);
 }
 
 struct Chunk {
@@ -148,6 +149,7 @@ struct bp_vjob {
   Pool* pool;
   void* pinned = nullptr;
   bool loaded = false;
+  bool fsdev = false;  // the transcript on the device (vbatch_run_fsdev_async): set at creation, off for the latency path
   // bp_vjob_submit / bp_vjob_wait: the run driven by a thread of its own, so that a second job's pass can fill the
   // GPU while this one's drains
   std::thread driver;
@@ -204,6 +206,7 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
   job->m = m;
   job->batch = batch;
   job->style = (ShowStyle)ctx->show_style;
+  job->fsdev = fs_device_enabled();
   job->pool = new Pool(host_threads > 0 ? host_threads : default_threads());
   job->chunks.resize(n_chunks);
   size_t per = (batch + n_chunks - 1) / n_chunks;
@@ -243,6 +246,7 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     ch.vb->direct_host = true;  // acc / verdict above are pinned: the kernels store to them directly
     Pool* pool = job->pool;
     ch.vb->pfor = [pool](size_t n, const std::function<void(size_t, size_t)>& f) { pool->run(f, n, 4); };
+    job->fsdev = job->fsdev && !ch.vb->split;
   }
   *out = job;
   return BP_OK;
@@ -364,9 +368,7 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   // The transcript on the device (BP_FS_DEVICE, default on): every chunk's pass is one in-order sequence of kernels,
   // challenges included, and the host only collects verdicts.  The latency path of small batches keeps the host
   // transcript (its chains run one lane per scalar bit and hand XYZZ sums to the host anyway).
-  bool fsdev = fs_device_enabled();
-  for (auto& ch : job->chunks) fsdev = fsdev && !ch.vb->split;
-  if (fsdev) {
+  if (job->fsdev) {
     for (auto& ch : job->chunks)
       if ((rc = vbatch_run_fsdev_async(ch.vb, ch.verdict)) != BP_OK) {
         err = ctx->err;

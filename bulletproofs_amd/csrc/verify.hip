@@ -378,6 +378,13 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
   const bool live = p < d.B;
   const size_t B = d.B, ES = B * 64;  // stride between table entries of one proof
   u256 run = u256_one();
+  bool need_inv = false;  // uniform: some table of the range holds two points (a single point's table is inversion-free)
+#pragma unroll 1
+  for (uint32_t r = t_lo; r < t_hi; r++) {
+    int ra, rb;
+    joint_table_rows(d, r, ra, rb);
+    need_inv = need_inv || (r != t_skip && rb >= 0);
+  }
 #pragma unroll 1
   for (uint32_t r = t_lo; live && r < t_hi; r++) {
     if (r == t_skip) continue;
@@ -387,20 +394,20 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
     affine L = ld_affine(pts + ((size_t)ra * B + p) * 64);
     st_affine(T + 0 * ES, L);
     st_affine(T + 1 * ES, glv_phi(L));
-    if (rb >= 0) {
-      affine Rp = ld_affine(pts + ((size_t)rb * B + p) * 64);
-      st_affine(T + 3 * ES, Rp);
-      st_affine(T + 7 * ES, glv_phi(Rp));
-    }
-    const int e_end = rb >= 0 ? 16 : 4;
+    st_affine(T + 2 * ES, glv_p_plus_phi(L));  // entry 3 = P0 + phi(P0), no addition needed
+    if (rb < 0) continue;
+    affine Rp = ld_affine(pts + ((size_t)rb * B + p) * 64);
+    st_affine(T + 3 * ES, Rp);
+    st_affine(T + 7 * ES, glv_phi(Rp));
+    st_affine(T + 11 * ES, glv_p_plus_phi(Rp));  // entry 12 = P1 + phi(P1)
 #pragma unroll 1
-    for (int e = 3; e < e_end; e++) {
+    for (int e = 5; e < 16; e++) {
       int top = 31 - __builtin_clz((unsigned)e);
       int rest = e & ~(1 << top);
-      if (rest == 0) continue;
+      if (rest == 0 || e == 12) continue;
       affine qt = ld_affine(T + (size_t)((1 << top) - 1) * ES);
       xyzz base;
-      if ((rest & (rest - 1)) == 0) {
+      if ((rest & (rest - 1)) == 0 || rest == 3) {  // an entry that is affine already
         base = xyzz_from_affine(ld_affine(T + (size_t)(rest - 1) * ES));
       } else {
         int rtop = 31 - __builtin_clz((unsigned)rest);
@@ -413,6 +420,7 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
       if (!xyzz_is_inf(v)) run = fq_mul(run, v.ZZZ);
     }
   }
+  if (!need_inv) return;
   // run is a product of non-zero ZZZ values; the workgroup shares one inversion (batchinv.h)
   u256 inv = block_batch_inverse<FqInvOps>(run, inv_lds);
   if (!live) return;
@@ -422,10 +430,11 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
     uint8_t* T = rtab + ((size_t)rr * 15 * B + p) * 64;
     int ra, rb;
     joint_table_rows(d, rr, ra, rb);
+    if (rb < 0) continue;
 #pragma unroll 1
-    for (int e = rb >= 0 ? 15 : 3; e >= 3; e--) {
+    for (int e = 15; e >= 5; e--) {
       int top = 31 - __builtin_clz((unsigned)e);
-      if ((e & ~(1 << top)) == 0) continue;
+      if ((e & ~(1 << top)) == 0 || e == 12) continue;
       size_t slot = ((size_t)rr * 11 + composite_index(e, top)) * B + p;
       xyzz v = ld_xyzz(&rtx[slot]);
       affine a = affine_inf();
@@ -1394,7 +1403,9 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
   if (side) BP_TRY(hipEventRecord(vb->fs_ev[2], sd));
   hipLaunchKernelGGL(k_vprep1, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->zpow, vb->dig1);
   const uint32_t lpp = vbatch_lpp(d.B);
+  prof_begin(vb, 0, vb->nt1);
   launch_fixed(vb, B * lpp, vb->nt1, lpp, vb->dig1, vb->tb1, vb->acc1);
+  prof_end(vb, 0);
   if (pair)
     hipLaunchKernelGGL(k_stage1_tail_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, strm, d, vb->pts,
                        vb->cst, vb->acc1, (uint8_t*)vb->vtab, vb->acc_aff, (uint8_t*)nullptr, (uint8_t*)nullptr);
@@ -1414,7 +1425,9 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
   }
   hipLaunchKernelGGL(k_vprep3a, VB_GRID(B), d, vb->xk_m, vb->xkinv_m, vb->cst, vb->stab);
   hipLaunchKernelGGL(k_vprep3, VB_GRID((size_t)d.nm * B), d, vb->sc, vb->cst, vb->ypowinv, vb->stab, vb->dig3a);
+  prof_begin(vb, 1, vb->nt3a);
   launch_fixed(vb, B * lpp, vb->nt3a, lpp, vb->dig3a, vb->tb3a, vb->acc1);
+  prof_end(vb, 1);
   if (side) BP_TRY(hipStreamWaitEvent(strm, vb->fs_ev[2], 0));  // acc2 of the t-check
   uint8_t* direct = vb->direct_host ? verdicts : nullptr;
   hipLaunchKernelGGL(k_verdict, VB_GRID(B), d, vb->acc1, vb->acc2, vb->acc_aff, (const xyzz*)nullptr, vb->bad, vb->verdict,
