@@ -15,7 +15,7 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CY
 cd $R
 python benchmarks/prof_summary.py $(find $OUT/trace -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
 python benchmarks/prof_overlap.py $(find $OUT/trace -name "*.db" | head -1) | head -1 > $OUT/overlap.txt
-python benchmarks/prof_window.py $(find $OUT/trace -name "*.db" | head -1) 4 > $OUT/steady_window.txt || true
+python benchmarks/prof_window.py $(find $OUT/trace -name "*.db" | head -1) 1 > $OUT/steady_window.txt || true
 python benchmarks/pmc_summary.py $(find $OUT/fetch -name "*.db" | head -1) > $OUT/pmc_fetch.txt
 python benchmarks/pmc_summary.py $(find $OUT/write -name "*.db" | head -1) > $OUT/pmc_write.txt
 python benchmarks/pmc_summary.py $(find $OUT/sq -name "*.db" | head -1) > $OUT/pmc_sq.txt

@@ -1388,6 +1388,7 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
   // the t-check) and the t-polynomial check (wants y, z, x: k_vprep0's constants).  Its chains run beside the main
   // stream's, a second wave on the SIMDs.  BP_FS_SIDE=0 keeps everything on one stream.
   static const bool side_env = !(getenv("BP_FS_SIDE") && atoi(getenv("BP_FS_SIDE")) == 0);
+  static const bool fs_round_batchinv = getenv("BP_ROUND_BATCHINV") && atoi(getenv("BP_ROUND_BATCHINV")) != 0;
   const bool side = side_env && vb->aux != strm;
   hipStream_t sd = side ? vb->aux : strm;
   hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, sd), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, 0u, joint_tables(d), d.k);
@@ -1419,6 +1420,9 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
     if (pair)
       hipLaunchKernelGGL(k_round_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, strm, d, r, vb->xk,
                          vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, (uint8_t*)nullptr, (uint8_t*)nullptr);
+    else if (fs_round_batchinv)
+      hipLaunchKernelGGL(k_round<true>, VB_GRID(B), d, r, vb->xk, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff,
+                         (uint8_t*)nullptr, (uint8_t*)nullptr);
     else
       hipLaunchKernelGGL(k_round<false>, VB_GRID(B), d, r, vb->xk, vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff,
                          (uint8_t*)nullptr, (uint8_t*)nullptr);
