@@ -3,8 +3,8 @@
 // The verifier inverts one scalar-field and one base-field element per proof and round (x_k^-1 for
 // mkChallenges, /root/reference/Bulletproofs/InnerProductProof/Verifier.hs:47-50, and the affine form of
 // the running commitment that the next challenge hashes); the reference calls `recip` / the affine group
-// law once per element.  With one proof per lane every lane of a wave would run the same ~66 k-instruction
-// inversion loop.  Here the workgroup multiplies its elements together (prefix and suffix products by wave
+// law once per element.  With one proof per lane every lane of a wave would run the same inversion (~21 k
+// instructions by division steps, modinv30.h; ~66 k by Kaliski's almost-inverse before that).  Here the workgroup multiplies its elements together (prefix and suffix products by wave
 // shuffles, wave totals through LDS), ONE wave inverts the product, and every lane gets its own inverse as
 //   1/x_i = (1 / prod) * (prod of the elements before i) * (prod of the elements after i):
 // about 20 multiplications per lane; the other waves wait at a barrier and leave their issue slots to
@@ -13,18 +13,19 @@
 #include <hip/hip_runtime.h>
 #include "fe.h"
 #include "fq29.h"
+#include "modinv30.h"
 
 namespace bp {
 
 struct FqInvOps {
   static __device__ __forceinline__ u256 mul(const u256& a, const u256& b) { return fq_mul(a, b); }
-  static __device__ __forceinline__ u256 inv(const u256& a) { return fq_inv29(a); }  // Fermat chain on 29-bit limbs
+  static __device__ __forceinline__ u256 inv(const u256& a) { return fq_inv_gcd(a); }  // division steps (modinv30.h)
   static __device__ __forceinline__ u256 one() { return u256_one(); }
   static __device__ __forceinline__ bool is_zero(const u256& a) { return fq_is_zero(a); }
 };
 struct FrInvOps {  // Montgomery form in, Montgomery form out
   static __device__ __forceinline__ u256 mul(const u256& a, const u256& b) { return Fr::mul(a, b); }
-  static __device__ __forceinline__ u256 inv(const u256& a) { return Fr::inv(a); }
+  static __device__ __forceinline__ u256 inv(const u256& a) { return fr_inv_gcd(a); }
   static __device__ __forceinline__ u256 one() { return Fr::one(); }
   static __device__ __forceinline__ bool is_zero(const u256& a) { return u256_is_zero(a); }
 };

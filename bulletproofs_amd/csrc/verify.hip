@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_vprep0(VDims d, const uint8_t* __restri
       nmv.v[0] = d.nm;
       ysum = Fr::to_mont(nmv);
     } else {
-      ysum = Fr::mul(Fr::sub(ynm, Fr::one()), Fr::inv(ym1));
+      ysum = Fr::mul(Fr::sub(ynm, Fr::one()), fr_inv_gcd(ym1));
     }
   }
   // z^e, e = 0..m+2
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   u256 x = Fr::one();
   if (live) x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
   // x^-1 and, below, the affine form of the result: one inversion per workgroup each (batchinv.h)
-  u256 xinv = BATCH_INV ? block_batch_inverse<FrInvOps>(x, inv_lds) : Fr::inv(x);
+  u256 xinv = BATCH_INV ? block_batch_inverse<FrInvOps>(x, inv_lds) : fr_inv_gcd(x);
   xyzz acc = xyzz_inf();
   if (live) {
     const u256 x2 = Fr::sqr(x);
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     acc = xyzz_madd(acc, ld_affine(acc_aff + (size_t)p * 64));
   }
   const u256 zzz = live ? acc.ZZZ : u256_one();
-  u256 zi = BATCH_INV ? block_batch_inverse<FqInvOps>(zzz, inv_lds) : fq_inv29(zzz);
+  u256 zi = BATCH_INV ? block_batch_inverse<FqInvOps>(zzz, inv_lds) : fq_inv_gcd(zzz);
   affine out = affine_inf();
   if (live) {
     out = xyzz_to_affine_with_inv(acc, zi);
@@ -543,7 +543,7 @@ k_round_pair(VDims d, uint32_t round, const uint8_t* __restrict__ xk /*[B][32] c
   if (solo) {  // whole waves
     u256 x = Fr::one();
     if (live) x = Fr::to_mont(Fr::reduce_once(ld_u256(xk + (size_t)p * 32)));
-    const u256 xinv = Fr::inv(x);
+    const u256 xinv = fr_inv_gcd(x);
     GlvPos s0, s1;
 #pragma unroll
     for (int i = 0; i < 5; i++) s0.m1[i] = s0.m2[i] = s1.m1[i] = s1.m2[i] = 0;
@@ -604,7 +604,7 @@ k_round_pair(VDims d, uint32_t round, const uint8_t* __restrict__ xk /*[B][32] c
       a29.ZZZ.v[i] = xch[tid * 36 + 27 + i];
     }
     xyzz acc = xyzz_madd(xyzz29_to(a29), ld_affine(acc_aff + (size_t)p * 64));
-    out = xyzz_to_affine_with_inv(acc, fq_inv29(acc.ZZZ));
+    out = xyzz_to_affine_with_inv(acc, fq_inv_gcd(acc.ZZZ));
     st_affine(acc_aff + (size_t)p * 64, out);
     if (host_out) st_affine(host_out + (size_t)p * 64, out);
   }
@@ -701,7 +701,7 @@ k_stage1_tail_pair(VDims d, const uint8_t* __restrict__ pts, const u256* __restr
     }
     xyzz acc = xyzz_add(xyzz29_to(a29), ld_xyzz(&acc1[p]));
     acc = xyzz_madd(acc, ld_affine(pts + ((size_t)VP_A * B + p) * 64));
-    out = xyzz_to_affine_with_inv(acc, fq_inv29(acc.ZZZ));
+    out = xyzz_to_affine_with_inv(acc, fq_inv_gcd(acc.ZZZ));
     st_affine(acc_aff + (size_t)p * 64, out);
     if (host_out) st_affine(host_out + (size_t)p * 64, out);
   }

@@ -249,6 +249,16 @@ extern "C" void hs_dbl29_chain(const uint8_t* pt, int n, uint8_t* out) {
   sta(out, xyzz_to_affine(xyzz29_to(acc)));
 }
 
+// ---- safegcd inversion (modinv30.h) ----
+#include "../../bulletproofs_amd/csrc/modinv30.h"
+// which: 0 base field (weakly reduced input), 1 scalar field (canonical, plain), 2 scalar field in Montgomery form
+// (out = fr_inv_gcd(to_mont(a)) taken back out of Montgomery form)
+extern "C" void hs_modinv30(int which, const uint8_t* a, uint8_t* out) {
+  if (which == 0) st(out, fq_canon(fq_inv_gcd(ld(a))));
+  if (which == 1) st(out, modinv30(ld(a), modinv30_r()));
+  if (which == 2) st(out, Fr::from_mont(fr_inv_gcd(Fr::to_mont(ld(a)))));
+}
+
 // ---- device transcript (fsdev.h): the challenges of the range-proof verifier as the kernels form them ----
 #include "../../bulletproofs_amd/csrc/fsdev.h"
 // which: 0 shamirY (A,S)  1 shamirZ (A,S | y)  2 shamirX (A,S,T1,T2 | y,z)  3 shamirU (| tau,mu,t)  4 shamirX' (L,R,acc)
