@@ -14,7 +14,12 @@
 
 namespace bp {
 
-constexpr uint32_t FS_MSG_WORDS = 288;  // longest transcript (shamirX: 4 points, 2 scalars, derived style) + padding
+constexpr uint32_t FS_MSG_WORDS = 320;  // per proof: shamirX's message (4 points, 2 scalars, derived style: 842 bytes +
+                                        // padding, below 232 words) and, from word FS_U_WORD on, shamirU's (254 bytes)
+constexpr uint32_t FS_U_WORD = 232;
+// a hashed opening of a message, to be continued later: state (8 words), the bytes behind its last full block (16
+// words, zero beyond the text) and their count | full blocks << 8
+constexpr uint32_t FS_PRE_WORDS = 25;
 
 BP_HD uint32_t fs_rotr(uint32_t x, int n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -89,6 +94,7 @@ struct FsMsg {
   size_t stride;    // words between consecutive words of this lane
   uint32_t len;     // bytes written
   uint32_t cur;     // the bytes of the word being filled
+  uint32_t base;    // bytes of the message hashed before word 0 (behind the first block of `show _r`)
 };
 struct FsMark {  // a position to come back to (the messages of y, z, x share their opening text)
   uint32_t len, cur;
@@ -110,7 +116,7 @@ BP_HD void fs_rewind(FsMsg& m, const FsMark& k) {
 
 // the message opens with the 14 characters of `show _r` behind its first block: "41518161494337"
 BP_HD FsMsg fs_open(uint32_t* lane_word0, size_t stride) {
-  FsMsg m{lane_word0, stride, 0, 0};
+  FsMsg m{lane_word0, stride, 0, 0, 0};
   constexpr char T[15] = "41518161494337";
 #pragma unroll
   for (int i = 0; i < 14; i++) fs_put(m, (uint32_t)T[i]);
@@ -165,11 +171,24 @@ BP_HD void fs_put_point(FsMsg& m, int style, const u256& x, const u256& y) {
   if (style == 0) fs_put(m, ')');
 }
 
-// Pads the message in place (what lies behind its end is overwritten), hashes it from the state behind the first block
-// of `show _r`, and returns the digest as a scalar: big-endian integer mod r (2^256 < 2 r, one subtraction).
-// The message itself stays: a caller may rewind to a mark and go on writing.
-BP_HD u256 fs_finish_fr(FsMsg m) {
-  const uint64_t bits = (uint64_t)(m.len + FS_R_ABSORBED) * 8u;
+// Hashes the full 64-byte blocks written so far into st (no padding) and returns their number.
+BP_HD uint32_t fs_absorb_full_blocks(const FsMsg& m, uint32_t (&st)[8]) {
+  const uint32_t nblk = m.len / 64;
+#pragma unroll 1
+  for (uint32_t b = 0; b < nblk; b++) {
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = fs_bswap(m.w[(size_t)(b * 16 + i) * m.stride]);
+    fs_sha256_compress(st, w);
+  }
+  return nblk;
+}
+
+// Pads the message in place (what lies behind its end is overwritten), hashes blocks first_blk.. of the buffer on top
+// of st0 (the state behind everything before them) and returns the digest as a scalar: big-endian integer mod r
+// (2^256 < 2 r, one subtraction).  The message itself stays: a caller may rewind to a mark and go on writing.
+BP_HD u256 fs_finish_fr_from(FsMsg m, const uint32_t (&st0)[8], uint32_t first_blk) {
+  const uint64_t bits = (uint64_t)(m.base + m.len + FS_R_ABSORBED) * 8u;
   fs_put(m, 0x80u);
   while (m.len & 3u) fs_put(m, 0u);
   while ((m.len & 63u) != 56u) {
@@ -181,9 +200,10 @@ BP_HD u256 fs_finish_fr(FsMsg m) {
   m.len += 8;
   const uint32_t nblk = m.len / 64;
   uint32_t st[8];
-  fs_state_after_show_r_block(st);
+#pragma unroll
+  for (int i = 0; i < 8; i++) st[i] = st0[i];
 #pragma unroll 1
-  for (uint32_t b = 0; b < nblk; b++) {
+  for (uint32_t b = first_blk; b < nblk; b++) {
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = fs_bswap(m.w[(size_t)(b * 16 + i) * m.stride]);
@@ -193,6 +213,96 @@ BP_HD u256 fs_finish_fr(FsMsg m) {
 #pragma unroll
   for (int i = 0; i < 8; i++) dgst.v[i] = st[7 - i];
   return Fr::reduce_once(dgst);
+}
+BP_HD u256 fs_finish_fr(const FsMsg& m) {
+  uint32_t st[8];
+  fs_state_after_show_r_block(st);
+  return fs_finish_fr_from(m, st, 0);
+}
+
+// Saves the hashed opening of m (FS_PRE_WORDS words, `pstride` apart): the state behind its full blocks, the bytes
+// behind them, their count and the number of blocks.
+BP_HD void fs_save_opening(const FsMsg& m, uint32_t* pre, size_t pstride) {
+  uint32_t st[8];
+  fs_state_after_show_r_block(st);
+  const uint32_t nblk = fs_absorb_full_blocks(m, st);
+#pragma unroll
+  for (int i = 0; i < 8; i++) pre[(size_t)i * pstride] = st[i];
+  const uint32_t left = m.len - 64 * nblk;
+#pragma unroll 1
+  for (uint32_t i = 0; i < 16; i++) {
+    uint32_t word = 0;
+    if (4 * i + 4 <= left) word = m.w[(size_t)(nblk * 16 + i) * m.stride];
+    else if (4 * i < left) word = m.cur;
+    pre[(size_t)(8 + i) * pstride] = word;
+  }
+  pre[(size_t)24 * pstride] = left | (nblk << 8);
+}
+// A message that continues a saved opening: st receives the state to finish from
+BP_HD FsMsg fs_resume(const uint32_t* pre, size_t pstride, uint32_t* lane_word0, size_t stride, uint32_t (&st)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) st[i] = pre[(size_t)i * pstride];
+  const uint32_t info = pre[(size_t)24 * pstride], left = info & 0xFFu, nblk = info >> 8;
+  FsMsg m{lane_word0, stride, left, 0, 64 * nblk};
+#pragma unroll 1
+  for (uint32_t i = 0; i < 16; i++) {
+    const uint32_t word = pre[(size_t)(8 + i) * pstride];
+    if (4 * i + 4 <= left) m.w[(size_t)i * stride] = word;
+    else if (4 * i < left) m.cur = word;
+  }
+  return m;
+}
+
+// ---- the verifier's challenges --------------------------------------------------------------------------------------
+struct FsPoint {
+  u256 x, y;
+};
+// y, z, x of MultiRangeProof/Verifier.hs:31-33: shamirY = oracle (show _r <> A <> S), shamirZ = ... <> show y,
+// shamirX = show _r <> A <> S <> T1 <> T2 <> show y <> show z  (Utils.hs:145-165).  The three messages share
+// show _r <> A <> S: its full blocks are hashed once.
+BP_HD void fs_challenges_yzx(int style, const FsPoint& A, const FsPoint& S, const FsPoint& T1, const FsPoint& T2,
+                             uint32_t* lane_word0, size_t stride, u256& y, u256& z, u256& x) {
+  FsMsg m = fs_open(lane_word0, stride);
+  fs_put_point(m, style, A.x, A.y);
+  fs_put_point(m, style, S.x, S.y);
+  const FsMark as = fs_mark(m);
+  uint32_t st[8];
+  fs_state_after_show_r_block(st);
+  const uint32_t nb = fs_absorb_full_blocks(m, st);
+  y = fs_finish_fr_from(m, st, nb);
+  fs_rewind(m, as);
+  fs_put_fr(m, style, y);
+  z = fs_finish_fr_from(m, st, nb);
+  fs_rewind(m, as);
+  fs_put_point(m, style, T1.x, T1.y);
+  fs_put_point(m, style, T2.x, T2.y);
+  fs_put_fr(m, style, y);
+  fs_put_fr(m, style, z);
+  x = fs_finish_fr_from(m, st, nb);
+}
+// uChallenge = shamirU tBlinding mu t = oracle (show _r <> show tBlinding <> show mu <> show t)  (Utils.hs:172-174)
+BP_HD u256 fs_challenge_u(int style, const u256& tau, const u256& mu, const u256& t, uint32_t* lane_word0, size_t stride) {
+  FsMsg m = fs_open(lane_word0, stride);
+  fs_put_fr(m, style, tau);
+  fs_put_fr(m, style, mu);
+  fs_put_fr(m, style, t);
+  return fs_finish_fr(m);
+}
+// shamirX' acc L R = oracle (show _r <> L <> R <> acc)  (Utils.hs:167-170) in two parts: the opening show _r <> L <> R is
+// known with the proof and hashed ahead of time; the round itself appends the running commitment.
+BP_HD void fs_round_opening(int style, const FsPoint& L, const FsPoint& R, uint32_t* lane_word0, size_t stride,
+                            uint32_t* pre, size_t pstride) {
+  FsMsg m = fs_open(lane_word0, stride);
+  fs_put_point(m, style, L.x, L.y);
+  fs_put_point(m, style, R.x, R.y);
+  fs_save_opening(m, pre, pstride);
+}
+BP_HD u256 fs_round_challenge(int style, const uint32_t* pre, size_t pstride, const FsPoint& acc, uint32_t* lane_word0,
+                              size_t stride) {
+  uint32_t st[8];
+  FsMsg m = fs_resume(pre, pstride, lane_word0, stride, st);
+  fs_put_point(m, style, acc.x, acc.y);
+  return fs_finish_fr_from(m, st, 0);
 }
 
 }  // namespace bp

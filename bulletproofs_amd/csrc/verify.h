@@ -59,7 +59,7 @@ struct bp_vbatch {
   bp::u256 *cst, *ypowinv, *zpow, *xk_m /* x_k^2 */, *xkinv_m, *stab /* half-tables of the s-vector */;
   uint32_t *dig1, *dig3a, *dig3b, *tb1, *tb3a, *tb3b;
   bp::xyzz *acc1, *acc2, *vtab;  // vtab: S and phi(S) per proof (k_stage1_tail_pair)
-  uint32_t* fsmsg;               // message buffers of the device transcript (fsdev.h), FS_MSG_WORDS x B words
+  uint32_t *fsmsg, *fsmsg2, *fspre;  // device transcript (fsdev.h): message buffers, and the rounds' hashed openings
   // joint tables of the rounds, of S and of the t-check's terms (k_round_tables): affine entries, and the XYZZ
   // composites / running products they are normalised from
   uint8_t* rtab;

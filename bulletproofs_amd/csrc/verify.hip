@@ -962,59 +962,61 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 }
 
 // ---- the transcript on the device (fsdev.h): challenges formed where the proofs and the running commitment live -----
+__device__ __forceinline__ FsPoint ld_fspoint(const uint8_t* p) {
+  const affine a = ld_affine(p);
+  return FsPoint{a.x, a.y};
+}
 // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86) of every proof, from the loaded proof
-// alone; chal[4][B][32] is what vbatch_begin_async otherwise takes from the host.  msg: FS_MSG_WORDS x B words.
+// alone; chal[4][B][32] is what vbatch_begin_async otherwise takes from the host.  Lanes 0..B-1 walk the chain
+// y -> z -> x, lanes B..2B-1 hash u.  msg: FS_MSG_WORDS x B words.
 __global__ void __launch_bounds__(256) k_fs_initial(VDims d, int style, const uint8_t* __restrict__ sc, const uint8_t* __restrict__ pts,
                                                    uint32_t* __restrict__ msg, uint8_t* __restrict__ chal) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t B = d.B;
+  if (t >= 2 * d.B) return;
+  if (t < d.B) {
+    const uint32_t p = t;
+    u256 y, z, x;
+    fs_challenges_yzx(style, ld_fspoint(pts + ((size_t)VP_A * B + p) * 64), ld_fspoint(pts + ((size_t)VP_S * B + p) * 64),
+                      ld_fspoint(pts + ((size_t)VP_T1 * B + p) * 64), ld_fspoint(pts + ((size_t)VP_T2 * B + p) * 64),
+                      msg + p, B, y, z, x);
+    st_u256(chal + ((size_t)0 * B + p) * 32, y);
+    st_u256(chal + ((size_t)1 * B + p) * 32, z);
+    st_u256(chal + ((size_t)2 * B + p) * 32, x);
+  } else {
+    const uint32_t p = t - d.B;
+    const u256 u = fs_challenge_u(style, ld_u256(sc + ((size_t)VS_TAU * B + p) * 32), ld_u256(sc + ((size_t)VS_MU * B + p) * 32),
+                                  ld_u256(sc + ((size_t)VS_T * B + p) * 32), msg + (size_t)FS_U_WORD * B + p, B);
+    st_u256(chal + ((size_t)3 * B + p) * 32, u);
+  }
+}
+
+// The openings show _r <> L_r <> R_r of the rounds' messages, hashed ahead of the rounds (side stream):
+// pre[(r * FS_PRE_WORDS + w) * B + p].  buf: FS_OPEN_WORDS x B words.
+constexpr uint32_t FS_OPEN_WORDS = 96;  // 14 + 2 x 167 bytes of text
+__global__ void __launch_bounds__(256) k_fs_openings(VDims d, int style, const uint8_t* __restrict__ pts, uint32_t* __restrict__ buf,
+                                                    uint32_t* __restrict__ pre) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   const size_t B = d.B;
-  auto pt = [&](FsMsg& m, uint32_t row) {
-    const affine a = ld_affine(pts + ((size_t)row * B + p) * 64);
-    fs_put_point(m, style, a.x, a.y);
-  };
-  FsMsg m = fs_open(msg + p, B);
-  pt(m, VP_A);
-  pt(m, VP_S);
-  const FsMark as = fs_mark(m);
-  const u256 y = fs_finish_fr(m);  // shamirY: show _r <> A <> S   (Utils.hs:145-148)
-  fs_rewind(m, as);
-  fs_put_fr(m, style, y);
-  const u256 z = fs_finish_fr(m);  // shamirZ: ... <> show y   (Utils.hs:150-153)
-  fs_rewind(m, as);
-  pt(m, VP_T1);
-  pt(m, VP_T2);
-  fs_put_fr(m, style, y);
-  fs_put_fr(m, style, z);
-  const u256 x = fs_finish_fr(m);  // shamirX: show _r <> A <> S <> T1 <> T2 <> show y <> show z   (Utils.hs:155-165)
-  FsMsg mu = fs_open(msg + p, B);
-  fs_put_fr(mu, style, ld_u256(sc + ((size_t)VS_TAU * B + p) * 32));
-  fs_put_fr(mu, style, ld_u256(sc + ((size_t)VS_MU * B + p) * 32));
-  fs_put_fr(mu, style, ld_u256(sc + ((size_t)VS_T * B + p) * 32));
-  const u256 u = fs_finish_fr(mu);  // shamirU: show _r <> show tBlinding <> show mu <> show t   (Utils.hs:172-174)
-  st_u256(chal + ((size_t)0 * B + p) * 32, y);
-  st_u256(chal + ((size_t)1 * B + p) * 32, z);
-  st_u256(chal + ((size_t)2 * B + p) * 32, x);
-  st_u256(chal + ((size_t)3 * B + p) * 32, u);
+#pragma unroll 1
+  for (uint32_t r = 0; r < d.k; r++)
+    fs_round_opening(style, ld_fspoint(pts + ((size_t)(VP_L0 + r) * B + p) * 64),
+                     ld_fspoint(pts + ((size_t)(VP_L0 + d.k + r) * B + p) * 64), buf + p, B,
+                     pre + (size_t)r * FS_PRE_WORDS * B + p, B);
 }
 
 // x_r = shamirX' acc L_r R_r = oracle (show _r <> L_r <> R_r <> acc)  (mkChallenges, InnerProductProof/Verifier.hs:44-53;
-// Utils.hs:167-170), acc the running commitment the previous kernel left in acc_aff
-__global__ void __launch_bounds__(256) k_fs_round(VDims d, uint32_t round, int style, const uint8_t* __restrict__ pts,
+// Utils.hs:167-170): the hashed opening continued with acc, the running commitment the previous kernel left in acc_aff
+__global__ void __launch_bounds__(256) k_fs_round(VDims d, uint32_t round, int style, const uint32_t* __restrict__ pre,
                                                  const uint8_t* __restrict__ acc_aff, uint32_t* __restrict__ msg,
                                                  uint8_t* __restrict__ xk /*[B][32]*/) {
   __builtin_amdgcn_s_setprio(3);
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.B) return;
   const size_t B = d.B;
-  FsMsg m = fs_open(msg + p, B);
-  const affine L = ld_affine(pts + ((size_t)(VP_L0 + round) * B + p) * 64);
-  const affine Rr = ld_affine(pts + ((size_t)(VP_L0 + d.k + round) * B + p) * 64);
-  const affine acc = ld_affine(acc_aff + (size_t)p * 64);
-  fs_put_point(m, style, L.x, L.y);
-  fs_put_point(m, style, Rr.x, Rr.y);
-  fs_put_point(m, style, acc.x, acc.y);
-  st_u256(xk + (size_t)p * 32, fs_finish_fr(m));
+  st_u256(xk + (size_t)p * 32, fs_round_challenge(style, pre + (size_t)round * FS_PRE_WORDS * B + p, B,
+                                                  ld_fspoint(acc_aff + (size_t)p * 64), msg + p, B));
 }
 
 // Input validation at load time: bad[p] = 1 when proof p holds a point that is neither O nor a canonically encoded
@@ -1391,9 +1393,10 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
   static const bool fs_round_batchinv = getenv("BP_ROUND_BATCHINV") && atoi(getenv("BP_ROUND_BATCHINV")) != 0;
   const bool side = side_env && vb->aux != strm;
   hipStream_t sd = side ? vb->aux : strm;
+  if (d.k) hipLaunchKernelGGL(k_fs_openings, VB_GRID_ON(B, sd), d, style, vb->pts, vb->fsmsg2, vb->fspre);
   hipLaunchKernelGGL(k_round_tables, VB_GRID_ON(B, sd), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, 0u, joint_tables(d), d.k);
   if (side) BP_TRY(hipEventRecord(vb->fs_ev[1], sd));
-  hipLaunchKernelGGL(k_fs_initial, VB_GRID(B), d, style, vb->sc, vb->pts, vb->fsmsg, vb->chal);
+  hipLaunchKernelGGL(k_fs_initial, VB_GRID(2 * B), d, style, vb->sc, vb->pts, vb->fsmsg, vb->chal);
   hipLaunchKernelGGL(k_round_tables, VB_GRID(B), d, vb->pts, vb->rtx, vb->rpre, vb->rtab, d.k, d.k + 1, 0xFFFFFFFFu);
   hipLaunchKernelGGL(k_vprep0, VB_GRID(B), d, vb->chal, vb->cst, vb->ypowinv, vb->zpow, true);
   if (side) {
@@ -1416,7 +1419,7 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
   // the rounds read the side stream's tables
   if (side) BP_TRY(hipStreamWaitEvent(strm, vb->fs_ev[1], 0));
   for (uint32_t r = 0; r < d.k; r++) {
-    hipLaunchKernelGGL(k_fs_round, VB_GRID(B), d, r, style, vb->pts, vb->acc_aff, vb->fsmsg, vb->xk);
+    hipLaunchKernelGGL(k_fs_round, VB_GRID(B), d, r, style, vb->fspre, vb->acc_aff, vb->fsmsg, vb->xk);
     if (pair)
       hipLaunchKernelGGL(k_round_pair, dim3((unsigned)((B + RP_PROOFS - 1) / RP_PROOFS)), dim3(256), 0, strm, d, r, vb->xk,
                          vb->xk_m, vb->xkinv_m, vb->rtab, vb->acc_aff, (uint8_t*)nullptr, (uint8_t*)nullptr);
@@ -1558,6 +1561,8 @@ int bp::vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batc
     vb->acc2 = c.take<xyzz>(B);
     vb->vtab = c.take<xyzz>(B);  // S, phi(S) of k_stage1_tail_pair (128 bytes per proof)
     vb->fsmsg = c.take<uint32_t>((size_t)FS_MSG_WORDS * B);  // the device transcript's message buffers
+    vb->fsmsg2 = c.take<uint32_t>((size_t)FS_OPEN_WORDS * B);  // ... of the rounds' openings (side stream)
+    vb->fspre = c.take<uint32_t>((size_t)(d.k ? d.k : 1) * FS_PRE_WORDS * B);  // the hashed openings
     vb->rtx = c.take<xyzz>((size_t)11 * joint_tables(d) * B);
     vb->rpre = c.take<u256>((size_t)11 * joint_tables(d) * B);
     vb->rtab = c.take<uint8_t>((size_t)15 * joint_tables(d) * B * 64);

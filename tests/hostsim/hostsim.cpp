@@ -275,26 +275,25 @@ extern "C" void hs_fs_challenge(int style, int which, const uint8_t* pts, const 
   if (which == 4) { pt(0); pt(1); pt(2); }
   st(out, fs_finish_fr(m));
 }
-// y, z, x from one buffer with a rewind to the shared opening text, as k_fs_initial does
+// y, z, x as k_fs_initial forms them (shared opening hashed once), u, and a round's challenge in its two parts
+static FsPoint ldfp(const uint8_t* p) { return FsPoint{ld(p), ld(p + 32)}; }
 extern "C" void hs_fs_yzx(int style, const uint8_t* pts, size_t stride, uint8_t* out3) {
-  std::vector<uint32_t> buf((size_t)FS_MSG_WORDS * stride, 0);
-  FsMsg m = fs_open(buf.data(), stride);
-  fs_put_point(m, style, ld(pts), ld(pts + 32));
-  fs_put_point(m, style, ld(pts + 64), ld(pts + 96));
-  const FsMark as = fs_mark(m);
-  const u256 y = fs_finish_fr(m);
-  fs_rewind(m, as);
-  fs_put_fr(m, style, y);
-  const u256 z = fs_finish_fr(m);
-  fs_rewind(m, as);
-  fs_put_point(m, style, ld(pts + 128), ld(pts + 160));
-  fs_put_point(m, style, ld(pts + 192), ld(pts + 224));
-  fs_put_fr(m, style, y);
-  fs_put_fr(m, style, z);
-  const u256 x = fs_finish_fr(m);
+  std::vector<uint32_t> buf((size_t)FS_MSG_WORDS * stride, 0x5A5A5A5Au);
+  u256 y, z, x;
+  fs_challenges_yzx(style, ldfp(pts), ldfp(pts + 64), ldfp(pts + 128), ldfp(pts + 192), buf.data(), stride, y, z, x);
   st(out3, y);
   st(out3 + 32, z);
   st(out3 + 64, x);
+}
+extern "C" void hs_fs_u(int style, const uint8_t* scs, size_t stride, uint8_t* out) {
+  std::vector<uint32_t> buf((size_t)FS_MSG_WORDS * stride, 0x5A5A5A5Au);
+  st(out, fs_challenge_u(style, ld(scs), ld(scs + 32), ld(scs + 64), buf.data() + FS_U_WORD * stride, stride));
+}
+extern "C" void hs_fs_round(int style, const uint8_t* pts /*L, R, acc*/, size_t stride, size_t pstride, uint8_t* out) {
+  std::vector<uint32_t> buf((size_t)FS_MSG_WORDS * stride, 0x5A5A5A5Au), buf2((size_t)FS_MSG_WORDS * stride, 0xC3C3C3C3u);
+  std::vector<uint32_t> pre((size_t)FS_PRE_WORDS * pstride, 0x77777777u);
+  fs_round_opening(style, ldfp(pts), ldfp(pts + 64), buf.data(), stride, pre.data(), pstride);
+  st(out, fs_round_challenge(style, pre.data(), pstride, ldfp(pts + 128), buf2.data(), stride));
 }
 
 // ---- device decimal formatter (dec.h): 80-byte record of a 32-byte LE integer ----

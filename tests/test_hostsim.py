@@ -181,6 +181,13 @@ def test_device_transcript_matches_the_oracle(hs):
                 z = o.shamir_z(p4[0], p4[1], y)
                 x = o.shamir_x(p4[0], p4[1], p4[2], p4[3], y, z)
                 assert [int.from_bytes(out3.raw[32 * i:32 * i + 32], "little") for i in range(3)] == [y, z, x]
+                out = ctypes.create_string_buffer(32)
+                hs.hs_fs_u(style, b"".join(b(v) for v in s3), ctypes.c_size_t(stride), out)
+                assert int.from_bytes(out.raw, "little") == o.shamir_u(s3[0], s3[1], s3[2])
+                # the round's challenge from a hashed opening (show _r <> L <> R) continued with the commitment
+                hs.hs_fs_round(style, b"".join(pb(q) for q in p4[:3]), ctypes.c_size_t(stride),
+                               ctypes.c_size_t(rng.choice([1, 5, 64])), out)
+                assert int.from_bytes(out.raw, "little") == o.shamir_x_prime(p4[2], p4[0], p4[1])
     finally:
         o.SHOW_STYLE = old
 
