@@ -367,7 +367,10 @@ def main():
                     help="auto = weak (the headline); the split of BASELINE config 4 is then reported as strong_split")
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=0)
-    ap.add_argument("--pipe-chunks", type=int, default=0, help="chunks per job of the two-jobs-in-flight leg")
+    ap.add_argument("--pipe-chunks", type=int, default=0,
+                    help="chunks per job of the two-jobs-in-flight leg (0: 2 with the host transcript, 1 with the device's)")
+    ap.add_argument("--transcript", choices=["host", "device"], default="host",
+                    help="where the headline's Fiat-Shamir transcript is formed; the other form is reported beside it")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="transcript-hashing threads per rank (0 = min(16, usable cores / ranks on this host))")
     ap.add_argument("--pin", type=int, default=1, help="with several ranks on a host: restrict each rank to its own cores")
@@ -376,7 +379,10 @@ def main():
     ap.add_argument("--msm-min-logn", type=int, default=16)
     ap.add_argument("--extras", type=int, default=1, help="single-proof configs and API-inclusive rates at N = 1")
     a = ap.parse_args()
-    fs_device = os.environ.get("BP_FS_DEVICE", "1") != "0"   # the library's switch: transcript on the GPU (default)
+    # Where the headline's Fiat-Shamir transcript is formed: on the host's threads (north_star's form, the library's
+    # default) or on the GPU (BP_FS_DEVICE=1).  The library reads the variable when a job is created.
+    fs_device = a.transcript == "device"
+    os.environ["BP_FS_DEVICE"] = "1" if fs_device else "0"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -478,12 +484,10 @@ def main():
                                               "(creates and caches the job on the context), then a second call"))
     # Two jobs in flight (bp_vjob_submit / bp_vjob_wait): what a serving loop over a stream of 65,536-proof batches gets.
     # The headline above stays the synchronous step; this rate is reported beside it.  The hardware runs four of the
-    # library's streams side by side.  With the transcript on the device a job is one chunk (the library's default);
-    # with the host transcript (BP_FS_DEVICE=0) two jobs in flight want TWO chunks each: 21.8 ms per pass against
-    # 24.1 ms with four (benchmarks/pipe_sweep.sh) - pass --pipe-chunks 2 there.
-    pipelined = None
-    if a.extras:
-        pj = [eng.vjob(n_bits, 1, B, a.pipe_chunks, host_threads) for _ in range(2)]
+    # library's streams side by side, so with the host transcript two jobs in flight take TWO chunks each (four kernels
+    # of twice the width): 21.8 ms per pass against 24.1 ms with four chunks each (benchmarks/pipe_sweep.sh).
+    def two_in_flight(chunks):
+        pj = [eng.vjob(n_bits, 1, B, chunks, host_threads) for _ in range(2)]
         for j in pj:
             j.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
             check(j.run())
@@ -502,17 +506,55 @@ def main():
         dp = time.perf_counter() - t0
         for v in outs:
             check(v)
+        for j in pj:
+            j.close()
         if dist is not None:
             tp = torch.tensor([dp], dtype=torch.float64, device="cuda")
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             dp = float(tp.item())
+        return npass, dp
+
+    pipelined = None
+    other = None
+    if a.extras:
+        pc = a.pipe_chunks or (1 if fs_device else 2)
+        npass, dp = two_in_flight(pc)
         pipelined = dict(value=total * npass / dp, unit="verifies/s", passes=npass, ms_per_pass=dp / npass * 1e3,
-                         chunks_per_job=a.pipe_chunks or (1 if fs_device else 4),
+                         chunks_per_job=pc, transcript=a.transcript,
                          what="two jobs of %d proofs per GPU in flight on one context (bp_vjob_submit / bp_vjob_wait): "
                               "the latency-bound rounds of one pass run beside the wide kernels of the other; every "
                               "verdict checked" % B)
-        for j in pj:
-            j.close()
+        # The same workload with the transcript formed at the other place, reported beside the headline.
+        os.environ["BP_FS_DEVICE"] = "0" if fs_device else "1"
+        oj = eng.vjob(n_bits, 1, B, 0, host_threads)
+        oj.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
+        for _ in range(max(1, a.warmup)):
+            check(oj.run())
+        barrier()
+        t0 = time.perf_counter()
+        outs = [oj.run() for _ in range(a.steps)]
+        barrier()
+        do = time.perf_counter() - t0
+        for v in outs:
+            check(v)
+        oj.close()
+        if dist is not None:
+            to = torch.tensor([do], dtype=torch.float64, device="cuda")
+            dist.all_reduce(to, op=dist.ReduceOp.MAX)
+            do = float(to.item())
+        opc = 2 if fs_device else 1
+        onp, odp = two_in_flight(opc)
+        os.environ["BP_FS_DEVICE"] = "1" if fs_device else "0"
+        other = dict(transcript="host" if fs_device else "device", value=total * a.steps / do, unit="verifies/s",
+                     steps=a.steps, ms_per_step=do / a.steps * 1e3,
+                     two_jobs_in_flight=dict(value=total * onp / odp, ms_per_pass=odp / onp * 1e3, chunks_per_job=opc),
+                     what=("the same %d proofs per GPU and the same checks with the Fiat-Shamir transcript formed on the "
+                           "GPU (BP_FS_DEVICE=1: decimal text, SHA-256 and the challenges in HIP kernels, fsdev.h; a pass "
+                           "is one in-order kernel sequence with no host step, one chunk).  north_star keeps transcript "
+                           "hashing on the host and SURVEY.md 8f-1 allows the device form only as an explicit choice, so "
+                           "this rate is reported beside the headline, not as it; bit-exact challenges "
+                           "(tests/test_gpu_transcript_device.py)" % B) if not fs_device else
+                          "the same workload with the transcript hashed by the host's threads (the library's default)")
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -637,6 +679,8 @@ def main():
             }
         if pipelined:
             line["pipelined"] = pipelined
+        if other:
+            line["device_transcript" if not fs_device else "host_transcript"] = other
         if strong:
             line["strong_split"] = strong
         if api:

@@ -122,11 +122,13 @@ int default_threads() {
   return t > 16 ? 16 : t;
 }
 
-// BP_FS_DEVICE=0 keeps the Fiat-Shamir transcript on the host for every batch size.  Read when a job is created (the
-// job keeps its form), so one process can hold jobs of both forms.
+// Where the Fiat-Shamir transcript is formed.  The default keeps it on the host's threads (north_star: "transcript
+// hashing and protocol control stay on the host"; SURVEY.md 8f-1 allows a device-side SHA-256 + decimal kernel only as an
+// explicit choice).  BP_FS_DEVICE=1 is that choice: text, SHA-256 and challenges on the GPU (fsdev.h), a pass without a
+// host step.  Read when a job is created (the job keeps its form), so one process can hold jobs of both forms.
 bool fs_device_enabled() {
   const char* e = getenv("BP_FS_DEVICE");
-  return !(e && atoi(e) == 0);
+  return e && atoi(e) != 0;
 }
 
 struct Chunk {
@@ -194,8 +196,8 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
   BP_REQUIRE(out, "null pointer");
   *out = nullptr;
   BP_REQUIRE(batch >= 1, "batch must be >= 1");
-  // Host transcript: chunks ping-pong between host hashing and the GPU; four streams of the context's concurrent set
-  // overlap.  Device transcript (the default, fs_device_enabled): no host step inside a pass, so ONE chunk - its chain
+  // Host transcript (the default): chunks ping-pong between host hashing and the GPU; four streams of the context's
+  // concurrent set overlap.  Device transcript (BP_FS_DEVICE=1): no host step inside a pass, so ONE chunk - its chain
   // kernels then have a wave on every SIMD and its multi-exponentiations several.
   if (n_chunks == 0) n_chunks = fs_device_enabled() ? 1 : (batch >= 16384 ? 4 : (batch >= 4096 ? 2 : 1));
   BP_REQUIRE(n_chunks <= 64 && n_chunks <= batch, "n_chunks out of range");
@@ -365,9 +367,9 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   auto t_entry = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
 #define TRACE(what, c, r, t0) do { if (trace) fprintf(stderr, "[vjob] %-8s chunk %d round %d  %8.3f -> %8.3f ms\n", what, (int)(c), (int)(r), t0, now_ms()); } while (0)
-  // The transcript on the device (BP_FS_DEVICE, default on): every chunk's pass is one in-order sequence of kernels,
-  // challenges included, and the host only collects verdicts.  The latency path of small batches keeps the host
-  // transcript (its chains run one lane per scalar bit and hand XYZZ sums to the host anyway).
+  // The transcript on the device (BP_FS_DEVICE=1 when the job was created): every chunk's pass is one in-order
+  // sequence of kernels, challenges included, and the host only collects verdicts.  The latency path of small batches
+  // keeps the host transcript (its chains run one lane per scalar bit and hand XYZZ sums to the host anyway).
   if (job->fsdev) {
     for (auto& ch : job->chunks)
       if ((rc = vbatch_run_fsdev_async(ch.vb, ch.verdict)) != BP_OK) {
