@@ -271,6 +271,14 @@ int bp_rangeproof_verify_batch(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_
  *                   generators (`gs`, `hs` are infinite lists in the reference; derive more and call again). */
 int bp_rangeproof_verify(bp_ctx* ctx, const uint8_t* upper_bound, size_t ub_len, const uint8_t* v_commits, uint32_t m,
                          const uint8_t* proof_scalars, const uint8_t* proof_points, uint32_t k, uint8_t* verdict);
+/* bp_vjob_*         the batch job behind bp_rangeproof_verify_batch (map (verifyProof upperBound), MultiRangeProof/
+ *                   Verifier.hs:19-39): create (workspaces, pinned staging, hashing threads) / load (untimed upload) /
+ *                   run (the timed pass) / submit + wait (the pass on a driver thread of the job).  n_chunks = 0 and
+ *                   host_threads = 0 pick defaults.  Where the Fiat-Shamir transcript is formed is fixed when the job
+ *                   is created: on the host's threads (default; the reference's `oracle` / `shamir*`, Utils.hs:29-33,
+ *                   145-174, in C++), or - BP_FS_DEVICE=1 in the environment - by kernels on the GPU from the same
+ *                   bytes (no host step inside a pass, one chunk by default, no hashing threads used).  Verdicts are
+ *                   identical; batches on the latency path (<= 768 proofs) always use the host transcript. */
 typedef struct bp_vjob bp_vjob;
 int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uint32_t n_chunks, int host_threads,
                    bp_vjob** out);
