@@ -11,6 +11,7 @@
 // XYZZ points: identity <=> ZZ == 0 (mod p).
 #pragma once
 #include "fe.h"
+#include "modinv30.h"
 
 namespace bp {
 
@@ -175,7 +176,7 @@ BP_HD affine xyzz_to_affine_with_inv(const xyzz& p, const u256& zzz_inv) {
 }
 BP_HD affine xyzz_to_affine(const xyzz& p) {
   if (xyzz_is_inf(p)) return affine_inf();
-  return xyzz_to_affine_with_inv(p, fq_inv(p.ZZZ));
+  return xyzz_to_affine_with_inv(p, fq_inv_gcd(p.ZZZ));  // division steps (modinv30.h): a third of Kaliski's instructions
 }
 
 // Same group element?  (cross-multiplied comparison, no inversion)

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_fb_fill(const xyzz* __restrict__ starts
     st_u256(out + (size_t)d * 64, run);  // product of ZZZ_0..ZZZ_{d-1}
     run = fq_mul(run, ld_u256(&scratch[(size_t)d * nthreads + t].ZZZ));
   }
-  u256 inv = fq_inv(run);
+  u256 inv = fq_inv_gcd(run);
   for (int d = (int)blk - 1; d >= 0; d--) {
     xyzz e = ld_xyzz(&scratch[(size_t)d * nthreads + t]);
     u256 pre = ld_u256(out + (size_t)d * 64);

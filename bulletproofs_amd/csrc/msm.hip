@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256) k_msm_shift(const uint8_t* __restrict__ p
     u256 zzz = ld_u256(&scratch[(size_t)w * n + i].ZZZ);
     if (!fq_is_zero(zzz)) run = fq_mul(run, zzz);  // the identity (and anything that doubled into it) stays out
   }
-  u256 inv = fq_inv(run);
+  u256 inv = fq_inv_gcd(run);
   for (int w = W - 1; w >= 0; w--) {
     uint8_t* slot = out + ((size_t)w * n + i) * 64;
     xyzz e = ld_xyzz(&scratch[(size_t)w * n + i]);
@@ -884,7 +884,7 @@ __device__ __forceinline__ void window_combine_store(const MsmPlan& pl, LoadW lo
   const xyzz r = xyzz29_to(quad_gather(P));
   if (lane != 0) return;
   if (out_xyzz) st_xyzz(out_xyzz, r);
-  if (out_affine) st_affine(out_affine, xyzz_to_affine_with_inv(r, fq_inv29(r.ZZZ)));  // O: ZZZ = 0 -> (0, 0)
+  if (out_affine) st_affine(out_affine, xyzz_to_affine_with_inv(r, fq_inv_gcd(r.ZZZ)));  // O: ZZZ = 0 -> (0, 0)
 }
 __global__ void __launch_bounds__(64) k_final2(const xyzz* __restrict__ wsum2, MsmPlan pl, uint8_t* __restrict__ out_affine,
                                               xyzz* __restrict__ out_xyzz) {
