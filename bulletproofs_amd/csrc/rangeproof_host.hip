@@ -139,6 +139,7 @@ struct Chunk {
   uint8_t *sc = nullptr, *pts = nullptr, *chal = nullptr, *xk = nullptr, *acc = nullptr, *verdict = nullptr;
   // decimal text written by the kernels (dec.h records): the running commitment, and the rows L_r, R_r
   uint8_t *acc_txt = nullptr, *lr_txt = nullptr;
+  uint8_t* init_txt = nullptr;  // A, S, T1, T2 and tBlinding, mu, t (vbatch_init_text_async)
 };
 
 }  // namespace
@@ -226,7 +227,7 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     job->k = bp_vbatch_rounds(ch.vb);
     job->npts = bp_vbatch_point_rows(ch.vb);
     pinned_bytes += (size_t)ch.B * (5 * 32 + (size_t)job->npts * 64 + 4 * 32 + 32 + 64 + 1 + 160 +
-                                    (size_t)2 * job->k * 160) + 8 * 256;
+                                    (size_t)2 * job->k * 160 + 11 * 80) + 9 * 256;
   }
   if (hipHostMalloc(&job->pinned, pinned_bytes, hipHostMallocDefault) != hipSuccess) {
     job->pinned = nullptr;
@@ -245,6 +246,7 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
     ch.verdict = cv.take<uint8_t>(B);
     ch.acc_txt = cv.take<uint8_t>(B * 160);
     ch.lr_txt = cv.take<uint8_t>((size_t)2 * job->k * B * 160 + 16);
+    ch.init_txt = cv.take<uint8_t>(B * 11 * 80);
     ch.vb->direct_host = true;  // acc / verdict above are pinned: the kernels store to them directly
     Pool* pool = job->pool;
     ch.vb->pfor = [pool](size_t n, const std::function<void(size_t, size_t)>& f) { pool->run(f, n, 4); };
@@ -389,8 +391,24 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   // y, z, x (MultiRangeProof/Verifier.hs:31-33) and uChallenge (Verifier.hs:86)
   // Two proofs are hashed side by side (finish_fr_pair: interleaved SHA-256 chains); a lone last proof pairs
   // with itself in spare buffers.
+  // BP_INIT_TEXT=1: the GPU formats A, S, T1, T2, tBlinding, mu, t as well (vbatch_init_text_async) and the host only
+  // concatenates and hashes (0.6 instead of 1.5 ms per 16,384-proof chunk).  Off by default: measured twice, the pass
+  // gets SLOWER (24.5 against 23.2 ms) - the 1.5 ms per chunk are what staggers the four chunks, so that one chunk's
+  // wide multi-exponentiations run beside another's narrow round chains; started 0.6 ms apart they walk in step.
+  static const bool init_text_env = getenv("BP_INIT_TEXT") && atoi(getenv("BP_INIT_TEXT")) != 0;
   auto hash0 = [&](Chunk& ch) {
     const size_t B = ch.B;
+    const bool recs = init_text_env && !ch.vb->split;  // the kernels formatted the proof's own numbers (dec.h records)
+    const uint8_t* ptxt = ch.init_txt;
+    const uint8_t* stxt = ch.init_txt + 8 * B * 80;
+    auto put_point = [&](Msg& m, uint32_t row, size_t p) {
+      if (recs) m.point_rec(ptxt + ((size_t)row * B + p) * 160);
+      else m.point(ch.pts + ((size_t)row * B + p) * 64);
+    };
+    auto put_scalar = [&](Msg& m, uint32_t row, size_t p) {
+      if (recs) m.fr_rec(stxt + ((size_t)row * B + p) * 80);
+      else m.fr(ch.sc + ((size_t)row * B + p) * 32);
+    };
     job->pool->run(
         [&](size_t a, size_t b) {
           uint8_t buf0[MSG_SCRATCH], buf1[MSG_SCRATCH];
@@ -412,8 +430,8 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
             size_t as_len[2];
             for (int i = 0; i < 2; i++) {
               my[i].r();
-              my[i].point(ch.pts + ((size_t)VP_A * B + pr[i]) * 64);
-              my[i].point(ch.pts + ((size_t)VP_S * B + pr[i]) * 64);
+              put_point(my[i], VP_A, pr[i]);
+              put_point(my[i], VP_S, pr[i]);
               as_len[i] = my[i].len;
               sha_mid_advance(mid[i], bufs[i], as_len[i]);
             }
@@ -429,8 +447,8 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
             Msg mx[2] = {Msg(bufs[0], st), Msg(bufs[1], st)};
             for (int i = 0; i < 2; i++) {
               mx[i].len = as_len[i];
-              mx[i].point(ch.pts + ((size_t)VP_T1 * B + pr[i]) * 64);
-              mx[i].point(ch.pts + ((size_t)VP_T2 * B + pr[i]) * 64);
+              put_point(mx[i], VP_T1, pr[i]);
+              put_point(mx[i], VP_T2, pr[i]);
               mx[i].fr(y[i]);
               mx[i].fr(z[i]);
             }
@@ -439,9 +457,9 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
             Msg mu[2] = {Msg(bufs[0], st), Msg(bufs[1], st)};
             for (int i = 0; i < 2; i++) {
               mu[i].r();
-              mu[i].fr(ch.sc + ((size_t)VS_TAU * B + pr[i]) * 32);
-              mu[i].fr(ch.sc + ((size_t)VS_MU * B + pr[i]) * 32);
-              mu[i].fr(ch.sc + ((size_t)VS_T * B + pr[i]) * 32);
+              put_scalar(mu[i], VS_TAU, pr[i]);
+              put_scalar(mu[i], VS_MU, pr[i]);
+              put_scalar(mu[i], VS_T, pr[i]);
             }
             finish_fr_pair(mu[0], r_mid, u[0], mu[1], r_mid, u[1]);
           }
@@ -488,6 +506,10 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   // challenge-independent GPU work of every chunk first (the rounds' joint tables, the text of L_r, R_r): it
   // fills the GPU while the host hashes the first chunk's y, z, x, u.  (Formatting A, S, T1, T2, tBlinding, mu, t
   // on the GPU as well was measured slower: the first chunk then waits for its text, 31.9 against 31.0 ms.)
+  // ... and in front of it, on every chunk's own stream, the text of the numbers y, z, x, u hash from the proof itself
+  if (init_text_env)
+    for (auto& ch : job->chunks)
+      if (!ch.vb->split && (rc = vbatch_init_text_async(ch.vb, ch.init_txt)) != BP_OK) return rc;
   for (auto& ch : job->chunks)
     if ((rc = vbatch_prepare_async(ch.vb, ch.lr_txt)) != BP_OK) return rc;
   static const int sched_bias = [] {
@@ -530,6 +552,8 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
     Chunk& ch = job->chunks[pick];
     double t_h = now_ms();
     if (stage[pick] == 0) {
+      if (init_text_env && !ch.vb->split && (rc = vbatch_wait(ch.vb)) != BP_OK) return rc;  // the init text is in
+      TRACE("inittxt", pick, -1, t_h);
       hash0(ch);
       TRACE("hash0", pick, -1, t_h);
       if ((rc = vbatch_begin_async(ch.vb, ch.chal, ch.acc, ch.acc_txt, ch.lr_txt)) != BP_OK) return rc;

@@ -100,6 +100,8 @@ int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_co
 int vbatch_round_async(bp_vbatch* vb, uint32_t round, const uint8_t* x, uint8_t* out_commitment, uint8_t* out_text);
 // the pass's challenge-independent side work (L_r, R_r text into lr_text, the rounds' joint tables), ahead of begin
 int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text);
+// decimal records of A, S, T1, T2 ([4][B][2]) and tBlinding, mu, t ([3][B]) into pinned init_text, on the batch's stream
+int vbatch_init_text_async(bp_vbatch* vb, uint8_t* init_text);
 int vbatch_finish_async(bp_vbatch* vb, uint8_t* verdicts);
 // the whole pass with the Fiat-Shamir transcript on the device (fsdev.h): no host step between load and verdicts
 int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts);

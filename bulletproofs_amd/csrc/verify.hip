@@ -1181,6 +1181,22 @@ int vbatch_prepare_async(bp_vbatch* vb, uint8_t* lr_text) {
   return BP_OK;
 }
 
+// The decimal text of what y, z, x, u hash from the proof itself - A, S, T1, T2 (rows 0..3: records [row][p][2]) and
+// tBlinding, mu, t (records [8 B + row][p]) - into pinned host memory, on the batch's own stream (nothing else is
+// queued there when a pass starts, so the host gets the text after a fraction of a millisecond).
+int vbatch_init_text_async(bp_vbatch* vb, uint8_t* init_text) {
+  bp_ctx* ctx = vb->ctx;
+  if (vb->stage < 1 || !vb->direct_host) {
+    ctx->err = "bp_vbatch init text: needs a loaded batch with pinned outputs";
+    return BP_ERR_STATE;
+  }
+  const size_t B = vb->d.B;
+  hipLaunchKernelGGL(k_dec_numbers, VB_GRID(8 * B), vb->pts, (uint32_t)(8 * B), init_text);
+  hipLaunchKernelGGL(k_dec_numbers, VB_GRID(3 * B), vb->sc, (uint32_t)(3 * B), init_text + 8 * B * DEC_REC);
+  BP_TRY(hipGetLastError());
+  return BP_OK;
+}
+
 int vbatch_begin_async(bp_vbatch* vb, const uint8_t* challenges, uint8_t* out_commitment, uint8_t* out_text,
                        uint8_t* lr_text) {
   bp_ctx* ctx = vb->ctx;
