@@ -516,6 +516,9 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
     const char* e = getenv("BP_SCHED_BIAS");
     return e ? atoi(e) : -1;
   }();
+  // BP_STAGGER_US: chunk c does not begin before c x that many microseconds into the pass (diagnostic: how far apart
+  // the chunks' phases should be; by default the time y, z, x, u take to hash spaces them)
+  static const long stagger_us = getenv("BP_STAGGER_US") ? atol(getenv("BP_STAGGER_US")) : 0;
   std::vector<uint32_t> stage(nc, 0);
   size_t finished = 0;
   while (finished < nc) {
@@ -524,6 +527,7 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
     for (size_t c = 0; c < nc; c++) {
       if (stage[c] > k + 1) continue;  // verdicts pending or done
       if (stage[c] > 0 && !vbatch_ready(job->chunks[c].vb)) continue;
+      if (stage[c] == 0 && stagger_us > 0 && now_ms() * 1000.0 < (double)stagger_us * (double)c) continue;  // not yet
       // sched_bias < 0: the ready chunk that is furthest along; otherwise the least advanced one, with chunk c
       // handicapped by sched_bias * c stages (0: all chunks advance together; large: lowest index first)
       long key = sched_bias < 0 ? -(long)stage[c] : (long)stage[c] + (long)sched_bias * (long)c;
