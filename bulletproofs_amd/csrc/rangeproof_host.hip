@@ -392,9 +392,11 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   // Two proofs are hashed side by side (finish_fr_pair: interleaved SHA-256 chains); a lone last proof pairs
   // with itself in spare buffers.
   // BP_INIT_TEXT=1: the GPU formats A, S, T1, T2, tBlinding, mu, t as well (vbatch_init_text_async) and the host only
-  // concatenates and hashes (0.6 instead of 1.5 ms per 16,384-proof chunk).  Off by default: measured twice, the pass
-  // gets SLOWER (24.5 against 23.2 ms) - the 1.5 ms per chunk are what staggers the four chunks, so that one chunk's
-  // wide multi-exponentiations run beside another's narrow round chains; started 0.6 ms apart they walk in step.
+  // concatenates and hashes (0.95 instead of 1.55 ms per 16,384-proof chunk).  Off by default: the pass gets SLOWER,
+  // 24.5-24.7 against 23.1-23.3 ms (profiles/r06_host_transcript_stagger_sweep.txt).  With the side work of all chunks
+  // queued at the start of the pass the first chunk's text waits 3.3 ms behind 126 MB of L_r, R_r text on the host
+  // link; with the side work started per chunk (what this switch does) the GPU idles while the host hashes the first
+  // challenges; spacing the chunks by hand (BP_STAGGER_US) changes neither.
   static const bool init_text_env = getenv("BP_INIT_TEXT") && atoi(getenv("BP_INIT_TEXT")) != 0;
   auto hash0 = [&](Chunk& ch) {
     const size_t B = ch.B;
@@ -510,8 +512,11 @@ static int vjob_run_impl(bp_vjob* job, uint8_t* verdicts, std::string& err) {
   if (init_text_env)
     for (auto& ch : job->chunks)
       if (!ch.vb->split && (rc = vbatch_init_text_async(ch.vb, ch.init_txt)) != BP_OK) return rc;
-  for (auto& ch : job->chunks)
-    if ((rc = vbatch_prepare_async(ch.vb, ch.lr_txt)) != BP_OK) return rc;
+  // (with the init text on, a chunk's side work starts with its stage 1 instead - vbatch_begin_async queues it: the
+  // text of L_r, R_r is 31 MB per 16,384-proof chunk over the host link, and the init text must not wait behind it)
+  if (!init_text_env)
+    for (auto& ch : job->chunks)
+      if ((rc = vbatch_prepare_async(ch.vb, ch.lr_txt)) != BP_OK) return rc;
   static const int sched_bias = [] {
     const char* e = getenv("BP_SCHED_BIAS");
     return e ? atoi(e) : -1;
