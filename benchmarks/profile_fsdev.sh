@@ -6,6 +6,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_fs_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export BP_FS_DEVICE=1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 $R/benchmarks/pipelined_probe.py sync 6 65536 16 0 > $OUT/probe.txt 2> $OUT/trace.err
 cd $R
 python benchmarks/prof_summary.py $(find $OUT/trace -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt

@@ -214,6 +214,13 @@ extern "C" void hs_glv_pair_tab29(const uint8_t* ks, const uint8_t* ps, uint8_t*
   xyzz r = glv_pair_multiexp_tab29(ld(ks), ld(ks + 32), [&](int e) { return tab[e]; });
   sta(out, xyzz_to_affine(r));
 }
+// P + phi(P) by the closed form of glv.h
+extern "C" void hs_glv_p_plus_phi(const uint8_t* pt, uint8_t* out) {
+  affine r = glv_p_plus_phi(lda(pt));
+  r.x = fq_canon(r.x);
+  r.y = fq_canon(r.y);
+  sta(out, r);
+}
 // two joint tables on one doubling chain (glv_tables_multiexp29): ks = 4 scalars, present = 4 flags, ps = 4 points; an
 // absent term's point is not read (its table half is left as the identity)
 extern "C" void hs_glv_tables29(int nt, const uint8_t* ks, const uint8_t* present, const uint8_t* ps, uint8_t* out) {

@@ -245,6 +245,10 @@ def test_two_joint_tables_on_one_chain(hs):
         for present in ([1, 0], [1, 1]):
             for _ in range(3):
                 cases.append((1, [rng.choice(edge + [rng.randrange(R)] * 4) for _ in range(2)], present, pts[:2]))
+    for q in (A, C, o.point_neg(D), None, G):          # P + phi(P) = (beta^2 x, -y), the tables' free composite entry
+        out = ctypes.create_string_buffer(64)
+        hs.hs_glv_p_plus_phi(pb(q), out)
+        assert dp(out.raw) == (o.point_add(q, o.point_mul(q, LAMBDA)) if q else None)
     for nt, ks, present, pts in cases:
         out = ctypes.create_string_buffer(64)
         hs.hs_glv_tables29(nt, b"".join(b(k) for k in ks), bytes(present), b"".join(pb(q) for q in pts), out)
