@@ -628,6 +628,17 @@ BP_HD fe29 fe29_mul2(const fe29& a, const fe29& b, const fe29& cc, const fe29& d
   return fe29_reduce(c);
 }
 
+// a * b + e in one reduction: e (limbs < 2^32, e.g. the lazy negative of a class-N value) joins the low columns, so a
+// difference U - X of a fresh product and a stored value comes out of the reduction in class N - no separate
+// addition and normalisation (9 multiply-adds by one instead of ~40 instructions)
+BP_HD fe29 fe29_mul_add(const fe29& a, const fe29& b, const fe29& e) {
+  uint64_t c[17];
+  fe29_columns(c, a, b, std::integral_constant<bool, true>());
+#pragma unroll
+  for (int i = 0; i < 9; i++) mad29k(c[i], e.v[i], 1u);
+  return fe29_reduce(c);
+}
+
 // a * a + e for a of class N and a lazy e (limbs < 2^32) added to the low columns
 BP_HD fe29 fe29_sqr_add(const fe29& a, const fe29& e) {
   uint32_t d[9];
@@ -647,6 +658,25 @@ BP_HD fe29 fe29_sqr_add(const fe29& a, const fe29& e) {
   return fe29_reduce(c);
 }
 BP_HD fe29 fe29_sqr(const fe29& a) { return fe29_sqr_add(a, fe29_zero()); }
+// 3 a^2 for a of class N: the columns of the square (below 2^61.2) tripled before the reduction
+BP_HD fe29 fe29_sqr_x3(const fe29& a) {
+  uint32_t d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+  uint64_t c[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) c[k] = 0;
+#define BP_SQC(K, N, I0) dot29<N>(c[K], &d[I0], &a.v[(K) - (I0)]);
+  BP_SQC(1, 1, 0) BP_SQC(2, 1, 0) BP_SQC(3, 2, 0) BP_SQC(4, 2, 0) BP_SQC(5, 3, 0) BP_SQC(6, 3, 0) BP_SQC(7, 4, 0)
+  BP_SQC(8, 4, 0) BP_SQC(9, 4, 1) BP_SQC(10, 3, 2) BP_SQC(11, 3, 3) BP_SQC(12, 2, 4) BP_SQC(13, 2, 5) BP_SQC(14, 1, 6)
+  BP_SQC(15, 1, 7)
+#undef BP_SQC
+#pragma unroll
+  for (int i = 0; i < 9; i++) mad29(c[2 * i], a.v[i], a.v[i]);
+#pragma unroll
+  for (int k = 0; k < 17; k++) c[k] += c[k] << 1;
+  return fe29_reduce(c);
+}
 
 // a^(2^n)
 BP_HD fe29 fe29_sqr_n(fe29 a, int n) {
@@ -704,7 +734,7 @@ BP_HD xyzz29 xyzz29_inf() {
 
 // 2 p (dbl-2008-s-1 with a = 0) on lazy limbs:
 //   U = 2Y, V = U^2, W = U V, S = X V, M = 3 X^2, X3 = M^2 - 2S, Y3 = M (S - X3) - W Y, ZZ3 = V ZZ, ZZZ3 = W ZZZ
-// as 4 products, 2 squares, one square-and-add, one two-product reduction and one normalisation.  The identity
+// as 4 products, 2 squares (one tripled in its columns), one square-and-add and one two-product reduction.  The identity
 // (ZZ = 0) stays the identity: ZZ3 = V * 0; secp256k1 has no point with Y = 0.
 BP_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
   fe29 U;                                                     // 2Y < 2^30.001
@@ -713,11 +743,7 @@ BP_HD xyzz29 xyzz29_dbl(const xyzz29& p) {
   const fe29 V = fe29_sqr(U);                                 // cross terms 4 x 2^31 x 2^30 + 2^60: fits
   const fe29 W = fe29_mul(U, V);
   const fe29 S = fe29_mul(p.X, V);
-  const fe29 XX = fe29_sqr(p.X);
-  fe29 M;                                                     // 3 X^2 < 2^30.6 -> N
-#pragma unroll
-  for (int i = 0; i < 9; i++) M.v[i] = XX.v[i] * 3u;
-  M = fe29_norm(M);
+  const fe29 M = fe29_sqr_x3(p.X);                            // 3 X^2, class N
   fe29 S2;
 #pragma unroll
   for (int i = 0; i < 9; i++) S2.v[i] = S.v[i] << 1;
@@ -735,11 +761,11 @@ BP_HD xyzz29 xyzz29_add_exact(const xyzz29& p, const xyzz29& q) {
   return xyzz29_from(xyzz_add(xyzz29_to(p), xyzz29_to(q)));
 }
 BP_HD xyzz29 xyzz29_add(const xyzz29& p, const xyzz29& q) {
-  const fe29 U1 = fe29_mul(p.X, q.ZZ), U2 = fe29_mul(q.X, p.ZZ);
-  const fe29 S1 = fe29_mul(p.Y, q.ZZZ), S2 = fe29_mul(q.Y, p.ZZZ);
+  const fe29 U1 = fe29_mul(p.X, q.ZZ);
+  const fe29 S1 = fe29_mul(p.Y, q.ZZZ);
   const fe29 nS1 = fe29_neg(S1);
-  const fe29 Pd = fe29_norm(fe29_add(U2, fe29_neg(U1)));
-  const fe29 Rd = fe29_norm(fe29_add(S2, nS1));
+  const fe29 Pd = fe29_mul_add(q.X, p.ZZ, fe29_neg(U1));      // U2 - U1, class N
+  const fe29 Rd = fe29_mul_add(q.Y, p.ZZZ, nS1);              // S2 - S1
   const fe29 PP = fe29_sqr(Pd);
   const fe29 PPP = fe29_mul(Pd, PP);
   const fe29 Q = fe29_mul(U1, PP);
@@ -781,16 +807,15 @@ BP_HD xyzz29 xyzz29_madd_exact(const xyzz29& p, const affine& q, bool negate) {
 // acc + (+-q), q a FINITE affine point below 2^256 per coordinate (a table entry, an input point): madd-2008-s on lazy limbs
 //   U2 = x ZZ, S2 = y ZZZ, P = U2 - X, R = S2 - Y, PP = P^2, PPP = P PP, Q = X PP,
 //   X3 = R^2 - PPP - 2Q, Y3 = R (Q - X3) - Y PPP, ZZ3 = ZZ PP, ZZZ3 = ZZZ PPP
-// as 6 products, one square, one square-and-add, one two-product reduction and two normalisations.
+// as 6 products (two of them with the subtrahend folded into their low columns), one square, one square-and-add and one
+// two-product reduction.
 BP_HD xyzz29 xyzz29_madd(const xyzz29& p, const affine& q, bool negate) {
   const fe29 qx = fe29_from_u256(q.x);
   fe29 qy = fe29_from_u256(q.y);
   if (negate) qy = fe29_neg(qy);                              // < 2^30
-  const fe29 U2 = fe29_mul(qx, p.ZZ);                         // N
-  const fe29 S2 = fe29_mul(qy, p.ZZZ);                        // 2^30 x N -> N
   const fe29 nY = fe29_neg(p.Y);                              // < 2^30
-  const fe29 Pd = fe29_norm(fe29_add(U2, fe29_neg(p.X)));     // L -> N
-  const fe29 Rd = fe29_norm(fe29_add(S2, nY));                // L -> N
+  const fe29 Pd = fe29_mul_add(qx, p.ZZ, fe29_neg(p.X));      // U2 - X out of one reduction: N
+  const fe29 Rd = fe29_mul_add(qy, p.ZZZ, nY);                // S2 - Y (2^30 x N + 2^30): N
   const fe29 PP = fe29_sqr(Pd);
   const fe29 PPP = fe29_mul(Pd, PP);
   const fe29 Q = fe29_mul(p.X, PP);
