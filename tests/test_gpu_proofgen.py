@@ -55,12 +55,16 @@ def test_batch_of_generated_proofs_verifies(engine):
     assert (got == exp).all()
 
 
-def test_two_jobs_in_flight_give_the_same_verdicts(engine):
+@pytest.mark.parametrize("transcript", ["host", "device", "mixed"])
+def test_two_jobs_in_flight_give_the_same_verdicts(engine, transcript, monkeypatch):
     """bp_vjob_submit / bp_vjob_wait: two jobs overlapping on one context return exactly what bp_vjob_run returns for
     each of them, pass after pass (different batches, different corrupted proofs, chunked and single-chunk jobs), and
-    the state rules hold (no second pass, load or run while one is in flight; no wait without submit)."""
+    the state rules hold (no second pass, load or run while one is in flight; no wait without submit).  With the
+    transcript hashed by the host, formed on the device (BP_FS_DEVICE=1 when the job is created), and one job of each
+    form side by side."""
     import ctypes
     import proofgen
+    forms = {"host": ("0", "0"), "device": ("1", "1"), "mixed": ("1", "0")}[transcript]
     engine.set_generators(o.gs(128), o.hs(128), o.h())
     n = 64
     jobs, expect = [], []
@@ -71,6 +75,7 @@ def test_two_jobs_in_flight_give_the_same_verdicts(engine):
         sc[2, bad, 0] ^= 1
         exp = np.ones(B, dtype=np.uint8)
         exp[bad] = 0
+        monkeypatch.setenv("BP_FS_DEVICE", forms[len(jobs)])
         job = engine.vjob(n, 1, B, chunks, 4)
         job.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
         assert (np.frombuffer(job.run(), dtype=np.uint8) == exp).all()
