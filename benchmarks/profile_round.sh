@@ -3,11 +3,12 @@
 # + SQ issue counters of the same bench command.  Run on the GPU box from the repo root:  bash benchmarks/profile_round.sh r01d
 set -e
 TAG=${1:-r01}
+EXTRA=${2:-}   # e.g. "--transcript device"
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --msm-logn 20 --msm-min-logn 20 --extras 0"
+CMD="python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --msm-logn 20 --msm-min-logn 20 --extras 0 $EXTRA"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- $CMD > /dev/null 2> $OUT/fetch.err
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- $CMD > /dev/null 2> $OUT/write.err
