@@ -1400,8 +1400,11 @@ int vbatch_run_fsdev_async(bp_vbatch* vb, uint8_t* verdicts) {
   const size_t B = d.B;
   const int style = ctx->show_style;
   hipStream_t strm = vb->stream;
+  // Two lanes per proof in the chains (k_round_pair, k_stage1_tail_pair: a third more instructions for a shorter chain)
+  // while the job's single chunk leaves SIMDs without a wave: up to 32,768 proofs (16,384: 9.7 -> 8.4 ms, 32,768: 12.6
+  // -> 11.4 ms; 65,536: 17.5 -> 21.2 ms, so not there).  The host form, with four chunks in flight, stops at 8,192.
   static const int pair_env = getenv("BP_ROUND_PAIR") ? atoi(getenv("BP_ROUND_PAIR")) : -1;
-  const bool pair = pair_env < 0 ? B <= 8192 : pair_env != 0;
+  const bool pair = pair_env < 0 ? B <= 32768 : pair_env != 0;
   // The side stream carries what the main chain does not wait for: every joint table but S's (wanted by round 0 and by
   // the t-check) and the t-polynomial check (wants y, z, x: k_vprep0's constants).  Its chains run beside the main
   // stream's, a second wave on the SIMDs.  BP_FS_SIDE=0 keeps everything on one stream.
