@@ -530,11 +530,14 @@ def main():
         oj.load(sc.ctypes.data_as(ctypes.c_char_p), pts.ctypes.data_as(ctypes.c_char_p))
         for _ in range(max(1, a.warmup)):
             check(oj.run())
+        eng.profile(True)
         barrier()
         t0 = time.perf_counter()
         outs = [oj.run() for _ in range(a.steps)]
         barrier()
         do = time.perf_counter() - t0
+        o_ms, o_calls, o_madds = eng.profile_read(0)
+        eng.profile(False)
         for v in outs:
             check(v)
         oj.close()
@@ -548,6 +551,12 @@ def main():
         other = dict(transcript="host" if fs_device else "device", value=total * a.steps / do, unit="verifies/s",
                      steps=a.steps, ms_per_step=do / a.steps * 1e3,
                      two_jobs_in_flight=dict(value=total * onp / odp, ms_per_pass=odp / onp * 1e3, chunks_per_job=opc),
+                     roofline=(dict(kernel="bp::k_fixed_multiexp", launches=o_calls, avg_launch_ms=o_ms / o_calls,
+                                    achieved=o_madds * MODMUL_PER_MADD * MADS_PER_MODMUL / (o_ms * 1e-3) / 1e12,
+                                    peak=PEAK_TMAD, unit="Tmad/s",
+                                    frac=o_madds * MODMUL_PER_MADD * MADS_PER_MODMUL / (o_ms * 1e-3) / 1e12 / PEAK_TMAD,
+                                    what="the same accounting as `roofline` above, over this form's timed steps")
+                               if o_calls else None),
                      what=("the same %d proofs per GPU and the same checks with the Fiat-Shamir transcript formed on the "
                            "GPU (BP_FS_DEVICE=1: decimal text, SHA-256 and the challenges in HIP kernels, fsdev.h; a pass "
                            "is one in-order kernel sequence with no host step, one chunk).  north_star keeps transcript "

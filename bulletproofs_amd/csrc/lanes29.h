@@ -249,8 +249,7 @@ __device__ __forceinline__ pair29 pair_madd(const pair29& s, const uint8_t* entr
 #pragma unroll
   for (int i = 0; i < 8; i++) nz |= own.v[i];
   if (((nz | dpp_quad<0xB1>(nz)) == 0u)) return s;   // the identity; both lanes of the pair agree
-  const fe29 Q1 = fe29_mul(s.c1, fe29_from_u256(own));            // S2 | U2
-  const fe29 D = fe29_norm(fe29_add(Q1, fe29_neg(s.c0)));         // R | P
+  const fe29 D = fe29_mul_add(s.c1, fe29_from_u256(own), fe29_neg(s.c0));  // R = S2 - Y | P = U2 - X, out of one reduction
   const fe29 Q2 = fe29_sqr(D);                                    // RR | PP
   const fe29 Dx = pair_xchg(D), Q2x = pair_xchg(Q2);              // P | R,  PP | RR
   const fe29 PP = fe29_sel(odd, Q2, Q2x), RR = fe29_sel(odd, Q2x, Q2);
