@@ -1096,9 +1096,19 @@ static inline void launch_fixed(bp_vbatch* vb, size_t nthreads, uint32_t nterms,
     if (nblk > 1) hipLaunchKernelGGL(k_fixed_sum, dim3(vb->d.B), dim3(64), 0, strm, nblk, vb->fpart, acc);
     return;
   }
-  if (vb->d.wb == 20)
-    hipLaunchKernelGGL(k_fixed_multiexp<20>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
-  else if (vb->d.wb == 16)
+  if (vb->d.wb == 20) {
+    // diagnostic: BP_FIXED_LDS=<bytes> of unused dynamic LDS per workgroup lowers the kernel's occupancy (above 80 KB:
+    // one wave per SIMD), to tell a latency-bound gather from an issue-bound loop
+    static const int lds_pad = [] {
+      const char* e = getenv("BP_FIXED_LDS");
+      int v = e ? atoi(e) : 0;
+      if (v > 0)
+        (void)hipFuncSetAttribute((const void*)k_fixed_multiexp<20>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+      return v;
+    }();
+    hipLaunchKernelGGL(k_fixed_multiexp<20>, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), (size_t)lds_pad, strm,
+                       vb->d.B, nterms, lpp, dig, tb, table, acc);
+  } else if (vb->d.wb == 16)
     hipLaunchKernelGGL(k_fixed_multiexp<16>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
   else if (vb->d.wb == 12)
     hipLaunchKernelGGL(k_fixed_multiexp<12>, VB_GRID_ON(nthreads, strm), vb->d.B, nterms, lpp, dig, tb, table, acc);
