@@ -42,6 +42,10 @@ BP_HD MsmPlan msm_plan(int c, int bits = 256) {
 //   c = 13     0.70  0.71  0.78  0.90  1.02  1.18  1.47
 //   c = 14                 0.87  0.93  0.95  0.96  0.99
 //   c = 16                             0.94  0.99  0.99  0.98      (2^18: 1.15, 2^20: 2.09)
+// c = 15 has the same nine GLV windows as c = 16 and half the buckets, but its top window holds 10 bits instead of 2:
+// 512 buckets of ~4,000 entries each stretch k_accumulate from 1.00 to 1.59 ms at 2^20 while k_seg_reduce / k_final,
+// latency chains whose depth does not depend on the bucket count, stay at 0.22 / 0.28 ms (2.54 against 1.98 ms per
+// sum; 1.65 against 0.95 ms at 2^16.  profiles/r07_msm_window_15_ab.txt).
 // Windows below 13 bits leave the two-level sort (FINE_BITS) and cost 0.9-2.9 ms at these sizes; fewer, wider windows
 // also shorten the Horner chain.  Narrow windows remain reachable through `window_bits`.
 inline int msm_choose_c(size_t n) {
