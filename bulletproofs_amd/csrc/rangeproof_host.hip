@@ -213,11 +213,39 @@ int bp_vjob_create(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batch, uin
   job->pool = new Pool(host_threads > 0 ? host_threads : default_threads());
   job->chunks.resize(n_chunks);
   size_t per = (batch + n_chunks - 1) / n_chunks;
+  // diagnostic: BP_CHUNK_WEIGHTS="w0,w1,..." (one weight per chunk) sizes the chunks in those proportions, in multiples
+  // of 256 proofs, instead of equally
+  std::vector<size_t> sizes(n_chunks, 0);
+  {
+    std::vector<double> wts;
+    if (const char* e = getenv("BP_CHUNK_WEIGHTS")) {
+      for (const char* q = e; *q;) {
+        char* end = nullptr;
+        double v = strtod(q, &end);
+        if (end == q) break;
+        wts.push_back(v > 0 ? v : 0);
+        q = *end == ',' ? end + 1 : end;
+      }
+    }
+    double sum = 0;
+    for (double v : wts) sum += v;
+    size_t left = batch;
+    for (uint32_t c = 0; c < n_chunks; c++) {
+      size_t want = per;
+      if (wts.size() == n_chunks && sum > 0) want = ((size_t)((double)batch * wts[c] / sum) + 255) / 256 * 256;
+      if (want < 1) want = 1;
+      const size_t others = n_chunks - 1 - c;  // every later chunk keeps at least one proof
+      if (want + others > left) want = left - others;
+      if (c + 1 == n_chunks) want = left;
+      sizes[c] = want;
+      left -= want;
+    }
+  }
   size_t first = 0, pinned_bytes = 0;
   for (uint32_t c = 0; c < n_chunks; c++) {
     Chunk& ch = job->chunks[c];
     ch.first = first;
-    ch.B = (uint32_t)(first + per <= batch ? per : batch - first);
+    ch.B = (uint32_t)sizes[c];
     first += ch.B;
     int rc = vbatch_create_ex(ctx, n_bits, m, ch.B, true, &ch.vb);
     if (rc != BP_OK) {
