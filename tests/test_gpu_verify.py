@@ -2,6 +2,7 @@
 Fiat-Shamir hashing done by the oracle's transcript functions: every
 intermediate the reference exposes (computeLRCommitment, the mkChallenges
 accumulator of each round) and the final Bool are compared bit for bit."""
+import os
 import random
 
 import pytest
@@ -288,6 +289,17 @@ def test_host_layer_verify_batch(eng_gens):
         job.load(sc, pts)
         assert [b != 0 for b in job.run()] == exp
         assert [b != 0 for b in job.run()] == exp  # re-runnable
+        job.close()
+    # chunks of unequal size (BP_CHUNK_WEIGHTS, read when the job is created): sizes are rounded to 256 proofs and
+    # clamped so that every chunk keeps a proof - here 34, 1, 1, 1 and 35, 1, 1
+    for weights, chunks in [("1,5,0,2", 4), ("3,1,1", 3)]:
+        os.environ["BP_CHUNK_WEIGHTS"] = weights
+        try:
+            job = eng_gens.vjob(n, m, len(all_p), chunks, 2)
+        finally:
+            del os.environ["BP_CHUNK_WEIGHTS"]
+        job.load(sc, pts)
+        assert [b != 0 for b in job.run()] == exp
         job.close()
 
 
