@@ -732,6 +732,15 @@ BP_HD xyzz29 xyzz29_inf() {
   return r;
 }
 
+// the identity as every routine here leaves it: ZZ = 0 in ALL limbs (the fast formulas send ZZ3 = 0 (mod p) to the exact
+// routines, which return zero limbs)
+BP_HD bool xyzz29_is_inf(const xyzz29& p) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) o |= p.ZZ.v[i];
+  return o == 0;
+}
+
 // 2 p (dbl-2008-s-1 with a = 0) on lazy limbs:
 //   U = 2Y, V = U^2, W = U V, S = X V, M = 3 X^2, X3 = M^2 - 2S, Y3 = M (S - X3) - W Y, ZZ3 = V ZZ, ZZZ3 = W ZZZ
 // as 4 products, 2 squares (one tripled in its columns), one square-and-add and one two-product reduction.  The identity

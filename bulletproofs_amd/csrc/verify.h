@@ -63,8 +63,8 @@ struct bp_vbatch {
   // joint tables of the rounds, of S and of the t-check's terms (k_round_tables): affine entries, and the XYZZ
   // composites / running products they are normalised from
   uint8_t* rtab;
-  bp::xyzz* rtx;
-  bp::u256* rpre;
+  uint32_t* rtx;   // k_round_tables' composite entries on 29-bit limbs, [11 T][36][B]
+  uint32_t* rpre;  // ... and the running products of their ZZZ, [11 T][9][B]
   // small batches (B <= VSPLIT_MAX_B): latency path.  Every variable-base product runs one lane per scalar bit on the
   // bit tables sh[point][128] = 2^j * point of the proof's points (rows VP_S..), the running commitment stays in
   // XYZZ on the device (acc_x) and is normalised by the host from the pinned copy hx, and the host supplies the

@@ -342,8 +342,8 @@ __global__ void __launch_bounds__(64) k_fixed_sum(uint32_t nblk /* <= 64 */, con
 // Tables 0..k-1 are the rounds' (L_r, R_r); table k is S alone (stage 1's x * S); tables k+1.. pair up the terms of
 // the t-polynomial check, V_0..V_{m-1}, T1, T2 (the last one holds a single point when m + 2 is odd, i.e. m = 1).
 // A table of a single point has the entries 1..3 only.
-// The composite entries are formed in XYZZ (rtx) and normalised with ONE inversion per proof (Montgomery's trick
-// over all composite entries; rpre holds the running products).
+// The composite entries are formed in XYZZ on 29-bit limbs (rtx) and normalised with ONE inversion per proof
+// (Montgomery's trick over all composite entries; rpre holds the running products).
 __device__ __forceinline__ int composite_index(int e, int top) { return e - 2 - top; }  // 3,5,6,7,9..15 -> 0..10
 
 __host__ __device__ inline uint32_t vt_terms(const VDims& d) { return d.m + 2; }                    // V_j, T1, T2
@@ -369,15 +369,45 @@ __device__ __forceinline__ void joint_table_rows(const VDims& d, uint32_t t, int
   }
 }
 
+// limb-major staging of k_round_tables (word j of entry `slot` of proof p at (slot * words + j) * B + p: a wave's
+// accesses coalesce)
+__device__ __forceinline__ void st_fe29_soa(uint32_t* a, size_t B, const fe29& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) a[(size_t)i * B] = v.v[i];
+}
+__device__ __forceinline__ fe29 ld_fe29_soa(const uint32_t* a, size_t B) {
+  fe29 v;
+#pragma unroll
+  for (int i = 0; i < 9; i++) v.v[i] = a[(size_t)i * B];
+  return v;
+}
+__device__ __forceinline__ void st_xyzz29_soa(uint32_t* a, size_t B, const xyzz29& v) {
+  st_fe29_soa(a, B, v.X);
+  st_fe29_soa(a + 9 * B, B, v.Y);
+  st_fe29_soa(a + 18 * B, B, v.ZZ);
+  st_fe29_soa(a + 27 * B, B, v.ZZZ);
+}
+__device__ __forceinline__ xyzz29 ld_xyzz29_soa(const uint32_t* a, size_t B) {
+  xyzz29 v;
+  v.X = ld_fe29_soa(a, B);
+  v.Y = ld_fe29_soa(a + 9 * B, B);
+  v.ZZ = ld_fe29_soa(a + 18 * B, B);
+  v.ZZZ = ld_fe29_soa(a + 27 * B, B);
+  return v;
+}
+
+// The composite entries are sums on the nine 29-bit limbs of fq29.h (one mixed addition each, ~1,600 instructions
+// against ~2,300 on 8 x 32 limbs; Montgomery's trick and the normalisation on the same limbs).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
-k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx /*[11 T][B]*/,
-               u256* __restrict__ rpre /*[11 T][B]*/, uint8_t* __restrict__ rtab /*[15 T][B][64]*/,
+k_round_tables(VDims d, const uint8_t* __restrict__ pts, uint32_t* __restrict__ rtx /*[11 T][36][B]*/,
+               uint32_t* __restrict__ rpre /*[11 T][9][B]*/, uint8_t* __restrict__ rtab /*[15 T][B][64]*/,
                uint32_t t_lo, uint32_t t_hi, uint32_t t_skip /*tables t_lo <= t < t_hi except t_skip*/) {
   __shared__ u256 inv_lds[BATCHINV_LDS];
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = p < d.B;
   const size_t B = d.B, ES = B * 64;  // stride between table entries of one proof
-  u256 run = u256_one();
+  fe29 run = fe29_zero();
+  run.v[0] = 1;
   bool need_inv = false;  // uniform: some table of the range holds two points (a single point's table is inversion-free)
 #pragma unroll 1
   for (uint32_t r = t_lo; r < t_hi; r++) {
@@ -406,23 +436,25 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
       int rest = e & ~(1 << top);
       if (rest == 0 || e == 12) continue;
       affine qt = ld_affine(T + (size_t)((1 << top) - 1) * ES);
-      xyzz base;
+      xyzz29 base;
       if ((rest & (rest - 1)) == 0 || rest == 3) {  // an entry that is affine already
-        base = xyzz_from_affine(ld_affine(T + (size_t)(rest - 1) * ES));
+        base = xyzz29_from_affine(ld_affine(T + (size_t)(rest - 1) * ES), false);
       } else {
         int rtop = 31 - __builtin_clz((unsigned)rest);
-        base = ld_xyzz(&rtx[((size_t)r * 11 + composite_index(rest, rtop)) * B + p]);
+        base = ld_xyzz29_soa(rtx + ((size_t)r * 11 + composite_index(rest, rtop)) * 36 * B + p, B);
       }
-      xyzz v = xyzz_madd(base, qt);
-      size_t slot = ((size_t)r * 11 + composite_index(e, top)) * B + p;
-      st_xyzz(&rtx[slot], v);
-      stm(rpre, slot, run);
-      if (!xyzz_is_inf(v)) run = fq_mul(run, v.ZZZ);
+      // xyzz29_madd wants a finite entry: O (an L_r or R_r at infinity) leaves the sum as it is
+      const xyzz29 sum = xyzz29_madd(base, qt, false);
+      const xyzz29 v = affine_is_inf(qt) ? base : sum;
+      const size_t slot = (size_t)r * 11 + composite_index(e, top);
+      st_xyzz29_soa(rtx + slot * 36 * B + p, B, v);
+      st_fe29_soa(rpre + slot * 9 * B + p, B, run);
+      if (!xyzz29_is_inf(v)) run = fe29_mul(run, v.ZZZ);
     }
   }
   if (!need_inv) return;
   // run is a product of non-zero ZZZ values; the workgroup shares one inversion (batchinv.h)
-  u256 inv = block_batch_inverse<FqInvOps>(run, inv_lds);
+  fe29 inv = fe29_from_u256(block_batch_inverse<FqInvOps>(fe29_to_u256(run), inv_lds));
   if (!live) return;
 #pragma unroll 1
   for (uint32_t rr = t_hi; rr-- > t_lo;) {
@@ -435,13 +467,15 @@ k_round_tables(VDims d, const uint8_t* __restrict__ pts, xyzz* __restrict__ rtx 
     for (int e = 15; e >= 5; e--) {
       int top = 31 - __builtin_clz((unsigned)e);
       if ((e & ~(1 << top)) == 0 || e == 12) continue;
-      size_t slot = ((size_t)rr * 11 + composite_index(e, top)) * B + p;
-      xyzz v = ld_xyzz(&rtx[slot]);
+      const size_t slot = (size_t)rr * 11 + composite_index(e, top);
+      const xyzz29 v = ld_xyzz29_soa(rtx + slot * 36 * B + p, B);
       affine a = affine_inf();
-      if (!xyzz_is_inf(v)) {
-        u256 zi = fq_mul(inv, ldm(rpre, slot));  // 1 / ZZZ of this entry
-        inv = fq_mul(inv, v.ZZZ);
-        a = xyzz_to_affine_with_inv(v, zi);
+      if (!xyzz29_is_inf(v)) {
+        const fe29 zi = fe29_mul(inv, ld_fe29_soa(rpre + slot * 9 * B + p, B));  // 1 / ZZZ of this entry
+        inv = fe29_mul(inv, v.ZZZ);
+        const fe29 zz_inv = fe29_sqr(fe29_mul(v.ZZ, zi));  // 1 / ZZ = (ZZ / ZZZ)^2
+        a.x = fq_canon(fe29_to_u256(fe29_mul(v.X, zz_inv)));
+        a.y = fq_canon(fe29_to_u256(fe29_mul(v.Y, zi)));
       }
       st_affine(T + (size_t)(e - 1) * ES, a);
     }
@@ -1592,8 +1626,8 @@ int bp::vbatch_create_ex(bp_ctx* ctx, uint32_t n_bits, uint32_t m, uint32_t batc
     vb->fsmsg = c.take<uint32_t>((size_t)FS_MSG_WORDS * B);  // the device transcript's message buffers
     vb->fsmsg2 = c.take<uint32_t>((size_t)FS_OPEN_WORDS * B);  // ... of the rounds' openings (side stream)
     vb->fspre = c.take<uint32_t>((size_t)(d.k ? d.k : 1) * FS_PRE_WORDS * B);  // the hashed openings
-    vb->rtx = c.take<xyzz>((size_t)11 * joint_tables(d) * B);
-    vb->rpre = c.take<u256>((size_t)11 * joint_tables(d) * B);
+    vb->rtx = c.take<uint32_t>((size_t)11 * joint_tables(d) * 36 * B);
+    vb->rpre = c.take<uint32_t>((size_t)11 * joint_tables(d) * 9 * B);
     vb->rtab = c.take<uint8_t>((size_t)15 * joint_tables(d) * B * 64);
     {
       const size_t sb = B <= split_max ? B : 1;
